@@ -1,0 +1,277 @@
+/*
+ * rtr_hip.h -- C ABI of the MI355X (gfx950) wavefront path tracer.
+ *
+ * This is the drop-in boundary for ONE hot path of JiGuang283/Ray_Tracing-Rendering:
+ * the tile-threaded integrator loop behind
+ *     void Renderer::render(shared_ptr<hittable> world, shared_ptr<camera> cam,
+ *                           const color& background, RenderBuffer& target,
+ *                           const std::vector<shared_ptr<Light>>& lights)
+ * (reference src/renderer/renderer.h:30-102).  The reference has no C plugin ABI;
+ * the entry points below are what an FFI for that call would bind.  Plain
+ * pointers and sizes only: no C++ types, no torch types.
+ *
+ * Data model: the caller flattens the (immutable) scene graph into the POD
+ * arrays of `rtr_scene_desc`, uploads it once, then asks for linear mean
+ * radiance of a pixel region.  The host applies the reference's gamma-2 /
+ * clamp store (renderer.h:126-140) itself.
+ *
+ * All scene quantities are IEEE double, like the reference (core/vec3.h:88).
+ * All functions return RTR_OK (0) or a negative rtr_status; the text of the
+ * last failure of a context is available from rtr_last_error().  No exception
+ * crosses this boundary.
+ */
+#ifndef RTR_HIP_H
+#define RTR_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTR_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------- */
+/* status codes                                                              */
+typedef enum rtr_status {
+    RTR_OK = 0,
+    RTR_ERR_INVALID = -1,     /* bad argument / malformed scene            */
+    RTR_ERR_UNSUPPORTED = -2, /* scene uses a node/material the device lacks */
+    RTR_ERR_DEVICE = -3,      /* HIP runtime error                           */
+    RTR_ERR_NO_SCENE = -4,    /* render before upload                        */
+    RTR_ERR_CANCELLED = -5,   /* rtr_cancel() observed (partial image)       */
+    RTR_ERR_NOMEM = -6
+} rtr_status;
+
+/* ------------------------------------------------------------------------- */
+/* flattened scene graph                                                     */
+
+/* hittable nodes: one record per object of the reference's hittable graph
+ * (geometry/hittable.h:25-32).  Indices refer to rtr_scene_desc.nodes.
+ * The graph may be a DAG (bvh_node with left == right, bvh.h:68-69; a sphere
+ * that is both a world object and a medium boundary, scenes.cpp:255-258). */
+typedef enum rtr_node_type {
+    RTR_NODE_BVH = 0,           /* bvh_node        geometry/bvh.h:12-31        a=left b=right f[0..5]=box min,max */
+    RTR_NODE_LIST = 1,          /* hittable_list   geometry/hittable_list.h    a=first (into list_children) b=count */
+    RTR_NODE_TRANSLATE = 2,     /* translate       geometry/hittable.h:34-73   a=child f[0..2]=offset */
+    RTR_NODE_ROTATE_Y = 3,      /* rotate_y        geometry/hittable.h:75-156  a=child f[0]=sin f[1]=cos */
+    RTR_NODE_FLIP_FACE = 4,     /* flip_face       geometry/hittable.h:158-179 a=child */
+    RTR_NODE_MEDIUM = 5,        /* constant_medium geometry/constant_medium.h  a=boundary b=phase material f[0]=neg_inv_density */
+    RTR_NODE_SPHERE = 6,        /* sphere          geometry/sphere.h           a=material f[0..2]=center f[3]=radius */
+    RTR_NODE_MOVING_SPHERE = 7, /* moving_sphere   geometry/moving_sphere.h    a=material f[0..2]=c0 f[3..5]=c1 f[6]=t0 f[7]=t1 f[8]=radius */
+    RTR_NODE_XY_RECT = 8,       /* xy_rect         geometry/aarect.h:10-32     a=material f[0]=x0 f[1]=x1 f[2]=y0 f[3]=y1 f[4]=k */
+    RTR_NODE_XZ_RECT = 9,       /* xz_rect         geometry/aarect.h:34-54     a=material f[0]=x0 f[1]=x1 f[2]=z0 f[3]=z1 f[4]=k */
+    RTR_NODE_YZ_RECT = 10,      /* yz_rect         geometry/aarect.h:56-76     a=material f[0]=y0 f[1]=y1 f[2]=z0 f[3]=z1 f[4]=k */
+    RTR_NODE_TYPE_COUNT = 11
+} rtr_node_type;
+
+typedef struct rtr_node {
+    int32_t type; /* rtr_node_type */
+    int32_t a;
+    int32_t b;
+    int32_t reserved;
+    double f[10];
+} rtr_node; /* 96 bytes */
+
+/* materials (materials/material.h:72-439, geometry/constant_medium.h:12-29) */
+typedef enum rtr_material_type {
+    RTR_MAT_LAMBERTIAN = 0,    /* tex[0]=albedo */
+    RTR_MAT_METAL = 1,         /* f[0..2]=albedo f[3]=fuzz (already clamped <=1) */
+    RTR_MAT_DIELECTRIC = 2,    /* f[0]=ir */
+    RTR_MAT_DIFFUSE_LIGHT = 3, /* tex[0]=emit */
+    RTR_MAT_PBR = 4,           /* tex[0]=albedo tex[1]=roughness tex[2]=metallic tex[3]=normal_map or -1 */
+    RTR_MAT_ISOTROPIC = 5,     /* tex[0]=albedo */
+    RTR_MAT_TYPE_COUNT = 6
+} rtr_material_type;
+
+typedef struct rtr_material {
+    int32_t type;
+    int32_t tex[4];
+    int32_t reserved[3];
+    double f[4];
+} rtr_material; /* 64 bytes */
+
+/* textures (materials/texture.h:11-162) */
+typedef enum rtr_texture_type {
+    RTR_TEX_SOLID = 0,   /* f[0..2]=color */
+    RTR_TEX_CHECKER = 1, /* a=even texture b=odd texture */
+    RTR_TEX_NOISE = 2,   /* a=perlin table index f[0]=scale */
+    RTR_TEX_IMAGE = 3,   /* a=image index, or -1 = file missing (cyan fallback, texture.h:116-118) */
+    RTR_TEX_TYPE_COUNT = 4
+} rtr_texture_type;
+
+typedef struct rtr_texture {
+    int32_t type;
+    int32_t a;
+    int32_t b;
+    int32_t reserved;
+    double f[4];
+} rtr_texture; /* 48 bytes */
+
+/* perlin noise tables (materials/perlin.h:10-19,57-60) */
+typedef struct rtr_perlin {
+    double ranvec[256][3];
+    int32_t perm_x[256];
+    int32_t perm_y[256];
+    int32_t perm_z[256];
+} rtr_perlin; /* 9216 bytes */
+
+/* 8-bit RGB images for image_texture (materials/texture.h:96-107) */
+typedef struct rtr_image {
+    int32_t width;
+    int32_t height;
+    uint64_t offset; /* byte offset of texel (0,0) in rtr_scene_desc.image_bytes, rows of 3*width bytes */
+} rtr_image;
+
+/* lights (lighting/light.h:15-47) */
+typedef enum rtr_light_type {
+    RTR_LIGHT_QUAD = 0, /* QuadLight lighting/quad_light.h:9-92: f[0..2]=Q f[3..5]=u f[6..8]=v f[9..11]=intensity f[12..14]=normal f[15]=area */
+    RTR_LIGHT_TYPE_COUNT = 1
+} rtr_light_type;
+
+typedef struct rtr_light {
+    int32_t type;
+    int32_t reserved;
+    double f[16];
+} rtr_light; /* 136 bytes */
+
+/* thin-lens camera, the private state of renderer/camera.h:43-50 */
+typedef struct rtr_camera {
+    double origin[3];
+    double lower_left_corner[3];
+    double horizontal[3];
+    double vertical[3];
+    double u[3];
+    double v[3];
+    double w[3];
+    double lens_radius;
+    double time0;
+    double time1;
+} rtr_camera; /* 192 bytes */
+
+typedef struct rtr_scene_desc {
+    uint32_t abi_version; /* RTR_ABI_VERSION */
+    int32_t root;         /* node index of `world` */
+    int32_t n_nodes;
+    int32_t n_list_children;
+    int32_t n_materials;
+    int32_t n_textures;
+    int32_t n_perlin;
+    int32_t n_images;
+    int32_t n_lights;
+    int32_t reserved;
+    uint64_t n_image_bytes;
+    const rtr_node* nodes;
+    const int32_t* list_children; /* node indices, hittable_list order */
+    const rtr_material* materials;
+    const rtr_texture* textures;
+    const rtr_perlin* perlin;
+    const rtr_image* images;
+    const uint8_t* image_bytes;
+    const rtr_light* lights;
+    rtr_camera camera;
+    double background[3];
+} rtr_scene_desc;
+
+/* ------------------------------------------------------------------------- */
+/* render request                                                            */
+
+/* integrator ids follow the reference CLI (main.cpp:52,78-100) */
+#define RTR_INTEGRATOR_RR 1  /* RRPathInterator   renderer/rr_path_integrator.h:21-59  */
+#define RTR_INTEGRATOR_MIS 4 /* MISPathIntegrator renderer/mis_path_integrator.h:25-150 */
+
+/* device pipeline selection */
+#define RTR_PIPELINE_AUTO 0
+#define RTR_PIPELINE_MEGAKERNEL 1 /* one lane per pixel, in-register bounce loop     */
+#define RTR_PIPELINE_WAVEFRONT 2  /* SoA path pool in HBM, extend/shade/connect stages */
+
+typedef struct rtr_render_params {
+    int32_t image_width;  /* W of the full image (pixel (i,j), j=0 is the bottom row, renderer.h:69-74) */
+    int32_t image_height; /* H */
+    int32_t x0, y0;       /* region [x0,x1) x [y0,y1) to render                        */
+    int32_t x1, y1;
+    int32_t spp;          /* Renderer::set_samples (renderer.h:104)                    */
+    int32_t max_depth;    /* Integrator::set_max_depth, reference uses 50 (main.cpp:102) */
+    int32_t rr_start_depth; /* 3 (mis_path_integrator.h:237)                           */
+    int32_t integrator;   /* RTR_INTEGRATOR_*                                          */
+    uint32_t seed;        /* render seed; per-sample xorshift32 state = rtr_sample_seed() */
+    int32_t pipeline;     /* RTR_PIPELINE_*                                            */
+    /* tile sharding (renderer.h:40-62): the image is cut in 16x16 tiles, numbered in
+     * the reference's dispatch order; this call renders the tiles with
+     * index % tile_stride == tile_first that intersect the region.  tile_stride <= 1
+     * renders every tile. */
+    int32_t tile_first;
+    int32_t tile_stride;
+    int32_t reserved[2];
+} rtr_render_params;
+
+typedef struct rtr_render_stats {
+    uint64_t samples;          /* camera samples finished                               */
+    uint64_t closest_segments; /* closest-hit traversals (hot loop 3)       */
+    uint64_t shadow_segments;  /* shadow-ray traversals                                 */
+    double device_ms;          /* HIP-event time of the render kernels of the last call */
+    int32_t kernel_launches;
+    int32_t pipeline;          /* pipeline that actually ran                            */
+} rtr_render_stats;
+
+typedef struct rtr_context rtr_context;
+
+/* ------------------------------------------------------------------------- */
+/* entry points                                                              */
+
+/* ABI version of the loaded library. */
+uint32_t rtr_abi_version(void);
+
+/* Number of HIP devices visible, or a negative status. */
+int rtr_device_count(void);
+
+/* Create / destroy a context bound to one GPU.  Replaces the construction of
+ * `Renderer` (renderer.h:22-24).  One context is driven by one host thread. */
+int rtr_create(int device_ordinal, rtr_context** out_ctx);
+void rtr_destroy(rtr_context* ctx);
+
+/* Launch the render kernels on an existing HIP stream (hipStream_t as void*;
+ * NULL = the context's own stream).  Lets a host framework time the kernels
+ * with its own events. */
+int rtr_set_stream(rtr_context* ctx, void* hip_stream);
+
+/* Validate + upload an immutable flattened scene.  Replaces the `world`, `cam`,
+ * `background`, `lights` arguments of Renderer::render (renderer.h:30-32). */
+int rtr_upload_scene(rtr_context* ctx, const rtr_scene_desc* scene);
+
+/* Render the region into a DEVICE buffer of doubles, 3 per pixel:
+ * d_rgb[((j - y0) * row_stride + (i - x0)) * 3 + c] = linear mean radiance
+ * (sum over samples * (1/spp)); pixels of tiles this call does not own are
+ * left untouched.  Asynchronous on the context stream unless `blocking`. */
+int rtr_render_device(rtr_context* ctx, const rtr_render_params* params,
+                      double* d_rgb, int64_t row_stride, int blocking);
+
+/* Same, into a HOST buffer (blocking; includes the D2H copy). */
+int rtr_render_host(rtr_context* ctx, const rtr_render_params* params,
+                    double* h_rgb, int64_t row_stride);
+
+/* Wait for everything queued on the context stream. */
+int rtr_synchronize(rtr_context* ctx);
+
+/* Thread-safe cooperative cancel (Renderer::cancel, renderer.h:113-115): the
+ * running render stops at its next wavefront iteration / batch boundary and
+ * returns RTR_ERR_CANCELLED. */
+int rtr_cancel(rtr_context* ctx);
+
+/* Statistics of the last finished render call (blocks until it is finished). */
+int rtr_get_stats(rtr_context* ctx, rtr_render_stats* out);
+
+/* Text of the last error on this context ("" if none).  ctx may be NULL for
+ * errors of rtr_create. */
+const char* rtr_last_error(const rtr_context* ctx);
+
+/* Per-sample RNG seed shared by the oracle and the device: the
+ * xorshift32 state (core/rtweekend.h:24-34) used for sample `s` of pixel
+ * (i, j) under render seed `seed`; never 0. */
+uint32_t rtr_sample_seed(uint32_t seed, int32_t image_width, int32_t i, int32_t j, int32_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTR_HIP_H */

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: regenerate tests/golden/ from the UNMODIFIED reference.
+
+Runs oracle/_ref/ref_harness (built by oracle/Makefile from /root/reference, which exists
+only in the build container) and writes small data fixtures: flattened scenes, RNG
+known-answer vectors, per-primitive/material/light vectors, per-sample Li records and
+small linear-radiance images.  Every fixture is data (inputs + the reference's outputs);
+no reference source text is stored.  The manifest records the exact command of each file.
+
+    python oracle/gen_golden.py            # needs /root/reference
+"""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+SCENE_SEED = 12345  # xorshift state before select_scene(): BVH axes, perlin tables, random geometry
+
+
+def run(*args):
+    cmd = [HARNESS] + [str(a) for a in args]
+    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+    return cmd, json.loads(out.strip().splitlines()[-1]) if out.strip().startswith("{") else {}
+
+
+def sha(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        subprocess.run(["make", "-C", HERE, "_ref/ref_harness"], check=True)
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {"scene_seed": SCENE_SEED, "generator": "oracle/gen_golden.py", "files": {}}
+
+    def note(name, cmd, info, **extra):
+        p = os.path.join(GOLD, name)
+        manifest["files"][name] = {"argv": [os.path.basename(cmd[0])] + cmd[1:-1] + [name], "info": info,
+                                   "sha256": sha(p), "bytes": os.path.getsize(p), **extra}
+
+    # RNG known answers
+    cmd, info = run("rng", os.path.join(GOLD, "rng.bin"))
+    note("rng.bin", cmd, info)
+
+    # flattened scenes (walked from the reference's own object graph)
+    for sid in (7, 21, 23, 9, 22):
+        name = "scene%02d.rtrs" % sid
+        path = os.path.join(GOLD, name)
+        cmd, info = run("dump-scene", sid, SCENE_SEED, path)
+        raw_sha = sha(path)
+        if os.path.getsize(path) > 100_000:  # scene 9 / 22: keep the repo small
+            with open(path, "rb") as f:
+                data = f.read()
+            with open(path + ".gz", "wb") as f:
+                f.write(gzip.compress(data, 9, mtime=0))
+            os.remove(path)
+            note(name + ".gz", cmd, info, raw_sha256=raw_sha)
+        else:
+            note(name, cmd, info, raw_sha256=raw_sha)
+
+    # closest-hit vectors on whole scenes
+    for sid, n in ((21, 1024), (23, 1024), (9, 1536)):
+        name = "hits_scene%02d.bin" % sid
+        cmd, info = run("hits", sid, SCENE_SEED, n, 777 + sid, os.path.join(GOLD, name))
+        note(name, cmd, info, scene=sid)
+
+    # material / light vectors
+    for sid, n in ((23, 96), (9, 48)):
+        name = "materials_scene%02d.bin" % sid
+        cmd, info = run("materials", sid, SCENE_SEED, n, 4242 + sid, os.path.join(GOLD, name))
+        note(name, cmd, info, scene=sid)
+    for sid, n in ((21, 256), (23, 256)):
+        name = "lights_scene%02d.bin" % sid
+        cmd, info = run("lights", sid, SCENE_SEED, n, 99 + sid, os.path.join(GOLD, name))
+        note(name, cmd, info, scene=sid)
+
+    # per-sample Li records and small images: (scene, integrator, W, spp, seed)
+    cases = [(7, 1, 64, 16, 1), (7, 4, 64, 16, 1), (21, 4, 64, 16, 1), (23, 4, 64, 16, 1), (9, 1, 64, 16, 1),
+             (22, 4, 64, 16, 1)]
+    for sid, integ, W, spp, seed in cases:
+        name = "li_scene%02d_i%d.bin" % (sid, integ)
+        cmd, info = run("li", sid, integ, W, spp, seed, SCENE_SEED, 2048, os.path.join(GOLD, name))
+        note(name, cmd, info, scene=sid, integrator=integ, width=W, spp=spp, seed=seed)
+        name = "img_scene%02d_i%d_%d_spp%d.f64" % (sid, integ, W, spp)
+        cmd, info = run("render", sid, integ, W, spp, seed, SCENE_SEED, os.path.join(GOLD, name), 8)
+        note(name, cmd, info, scene=sid, integrator=integ, width=W, height=info["height"], spp=spp, seed=seed)
+    # one mid-size image of the headline config's scene
+    name = "img_scene21_i4_128_spp32.f64"
+    cmd, info = run("render", 21, 4, 128, 32, 7, SCENE_SEED, os.path.join(GOLD, name), 8)
+    note(name, cmd, info, scene=21, integrator=4, width=128, height=info["height"], spp=32, seed=7)
+
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    total = sum(v["bytes"] for v in manifest["files"].values())
+    print("wrote %d fixtures, %.2f MB" % (len(manifest["files"]), total / 1e6))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

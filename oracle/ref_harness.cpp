@@ -1,0 +1,707 @@
+/*
+ * ref_harness.cpp -- TEST INFRASTRUCTURE (oracle/_ref), never part of the product.
+ *
+ * Own code that drives the UNMODIFIED reference sources where they lie under
+ * /root/reference (nothing is copied): it unity-includes scene/scenes.cpp so the
+ * geometry headers stay in one translation unit, is built with g++
+ * (RNG argument order), `-include oracle/shim_rtweekend.h` (settable
+ * RNG state) and `-fno-access-control` (to read private fields such as
+ * perlin tables, QuadLight and camera members when flattening).
+ *
+ * Sub-commands (all outputs are data files; see oracle/gen_golden.py):
+ *   info        <scene>                                    -> JSON on stdout
+ *   dump-scene  <scene> <scene_seed> <out.rtrs>            flatten the reference graph
+ *   render      <scene> <integ> <W> <spp> <seed> <scene_seed> <out.f64> [threads]
+ *   li          <scene> <integ> <W> <spp> <seed> <scene_seed> <n> <out.bin>
+ *   hits        <scene> <scene_seed> <n> <gen_seed> <out.bin>
+ *   materials   <scene> <scene_seed> <n_per_material> <gen_seed> <out.bin>
+ *   lights      <scene> <scene_seed> <n_per_light> <gen_seed> <out.bin>
+ *   rng         <out.bin>
+ *   time        <scene> <integ> <W> <spp>                  unseeded Renderer::render timing
+ *
+ * The pixel loop of `render`/`li` restates renderer/renderer.h:69-83 (the only
+ * reference lines not executed verbatim): per (pixel, sample) it sets the RNG
+ * state to rtr_sample_seed(), draws u, v, calls the reference's camera::get_ray
+ * and Integrator::Li, and accumulates in sample order.
+ */
+#include "scenes.cpp" /* reference: src/scene/scenes.cpp, found through -I */
+
+#include "direct_light_integrator.h"
+#include "mis_path_integrator.h"
+#include "path_integrator.h"
+#include "pbr_path_integrator.h"
+#include "rr_path_integrator.h"
+#include "camera.h"
+#ifdef RTR_REF_WITH_RENDERER
+#include "renderer.h"
+#endif
+
+#include "../include/rtr_scene_io.h"
+#include "../include/rtr_seed.h"
+#include "../include/rtr_testrec.h"
+
+#include <atomic>
+#include <chrono>
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#ifndef RTR_REF_UNSEEDED
+static inline void set_rng(uint32_t s) { rtr_ref_rng_state() = s; }
+static inline uint32_t get_rng() { return rtr_ref_rng_state(); }
+#endif
+
+static void die(const std::string& m) {
+    std::fprintf(stderr, "ref_harness: %s\n", m.c_str());
+    std::exit(2);
+}
+
+static shared_ptr<Integrator> make_integrator(int id) {
+    shared_ptr<Integrator> r;
+    switch (id) {
+    case 0: r = make_shared<PathIntegrator>(); break;
+    case 1: r = make_shared<RRPathInterator>(); break;
+    case 2: r = make_shared<PBRPathIntegrator>(); break;
+    case 3: r = make_shared<DirectLightIntegrator>(); break;
+    case 4: r = make_shared<MISPathIntegrator>(); break;
+    default: die("unknown integrator id");
+    }
+    r->set_max_depth(50); /* main.cpp:102 */
+    return r;
+}
+
+#ifndef RTR_REF_UNSEEDED
+/* ------------------------------------------------------------------------- */
+/* flatten the reference's object graph into the rtr_scene_desc POD form      */
+struct Flattener {
+    rtr_scene_storage out;
+    std::map<const hittable*, int> node_ix;
+    std::map<const material*, int> mat_ix;
+    std::map<const texture*, int> tex_ix;
+    std::vector<const material*> mats;
+
+    static void put3(double* f, const vec3& v) {
+        f[0] = v.x();
+        f[1] = v.y();
+        f[2] = v.z();
+    }
+
+    int tex(const texture* t) {
+        if (!t) return -1;
+        auto it = tex_ix.find(t);
+        if (it != tex_ix.end()) return it->second;
+        int ix = (int)out.textures.size();
+        tex_ix[t] = ix;
+        out.textures.push_back(rtr_texture{});
+        rtr_texture r{};
+        if (auto s = dynamic_cast<const solid_color*>(t)) {
+            r.type = RTR_TEX_SOLID;
+            put3(r.f, s->color_value);
+        } else if (auto c = dynamic_cast<const checker_texture*>(t)) {
+            r.type = RTR_TEX_CHECKER;
+            r.a = tex(c->even.get());
+            r.b = tex(c->odd.get());
+        } else if (auto n = dynamic_cast<const noise_texture*>(t)) {
+            r.type = RTR_TEX_NOISE;
+            r.a = (int)out.perlin.size();
+            r.f[0] = n->scale;
+            rtr_perlin p{};
+            for (int i = 0; i < 256; ++i) {
+                put3(p.ranvec[i], n->noise.ranvec[i]);
+                p.perm_x[i] = n->noise.perm_x[i];
+                p.perm_y[i] = n->noise.perm_y[i];
+                p.perm_z[i] = n->noise.perm_z[i];
+            }
+            out.perlin.push_back(p);
+        } else if (auto im = dynamic_cast<const image_texture*>(t)) {
+            r.type = RTR_TEX_IMAGE;
+            if (!im->data) {
+                r.a = -1;
+            } else {
+                r.a = (int)out.images.size();
+                rtr_image d{};
+                d.width = im->width;
+                d.height = im->height;
+                d.offset = out.image_bytes.size();
+                out.image_bytes.insert(out.image_bytes.end(), im->data,
+                                       im->data + (size_t)im->bytes_per_scanline * im->height);
+                out.images.push_back(d);
+            }
+        } else {
+            die("unsupported texture class in reference scene");
+        }
+        out.textures[ix] = r;
+        return ix;
+    }
+
+    int mat(const material* m) {
+        auto it = mat_ix.find(m);
+        if (it != mat_ix.end()) return it->second;
+        int ix = (int)out.materials.size();
+        mat_ix[m] = ix;
+        mats.push_back(m);
+        out.materials.push_back(rtr_material{});
+        rtr_material r{};
+        for (int k = 0; k < 4; ++k) r.tex[k] = -1;
+        if (auto l = dynamic_cast<const lambertian*>(m)) {
+            r.type = RTR_MAT_LAMBERTIAN;
+            r.tex[0] = tex(l->albedo.get());
+        } else if (auto me = dynamic_cast<const metal*>(m)) {
+            r.type = RTR_MAT_METAL;
+            put3(r.f, me->albedo);
+            r.f[3] = me->fuzz;
+        } else if (auto d = dynamic_cast<const dielectric*>(m)) {
+            r.type = RTR_MAT_DIELECTRIC;
+            r.f[0] = d->ir;
+        } else if (auto e = dynamic_cast<const diffuse_light*>(m)) {
+            r.type = RTR_MAT_DIFFUSE_LIGHT;
+            r.tex[0] = tex(e->emit.get());
+        } else if (auto p = dynamic_cast<const PBRMaterial*>(m)) {
+            r.type = RTR_MAT_PBR;
+            r.tex[0] = tex(p->albedo.get());
+            r.tex[1] = tex(p->roughness.get());
+            r.tex[2] = tex(p->metallic.get());
+            r.tex[3] = tex(p->normal_map.get());
+        } else if (auto i = dynamic_cast<const isotropic*>(m)) {
+            r.type = RTR_MAT_ISOTROPIC;
+            r.tex[0] = tex(i->albedo.get());
+        } else {
+            die("unsupported material class in reference scene");
+        }
+        out.materials[ix] = r;
+        return ix;
+    }
+
+    int list_node(int ix, const hittable_list& l) {
+        rtr_node r{};
+        r.type = RTR_NODE_LIST;
+        std::vector<int> kids;
+        for (const auto& o : l.objects) kids.push_back(node(o.get()));
+        r.a = (int)out.list_children.size();
+        r.b = (int)kids.size();
+        out.list_children.insert(out.list_children.end(), kids.begin(), kids.end());
+        out.nodes[ix] = r;
+        return ix;
+    }
+
+    int node(const hittable* h) {
+        auto it = node_ix.find(h);
+        if (it != node_ix.end()) return it->second;
+        int ix = (int)out.nodes.size();
+        node_ix[h] = ix;
+        out.nodes.push_back(rtr_node{});
+        rtr_node r{};
+        if (auto b = dynamic_cast<const bvh_node*>(h)) {
+            r.type = RTR_NODE_BVH;
+            put3(r.f, b->box.minimum);
+            put3(r.f + 3, b->box.maximum);
+            r.a = node(b->left.get());
+            r.b = node(b->right.get());
+        } else if (auto l = dynamic_cast<const hittable_list*>(h)) {
+            return list_node(ix, *l);
+        } else if (auto bx = dynamic_cast<const box*>(h)) {
+            return list_node(ix, bx->sides); /* box::hit == sides.hit (box.h:49-51) */
+        } else if (auto t = dynamic_cast<const translate*>(h)) {
+            r.type = RTR_NODE_TRANSLATE;
+            put3(r.f, t->offset);
+            r.a = node(t->ptr.get());
+        } else if (auto ro = dynamic_cast<const rotate_y*>(h)) {
+            r.type = RTR_NODE_ROTATE_Y;
+            r.f[0] = ro->sin_theta;
+            r.f[1] = ro->cos_theta;
+            r.a = node(ro->ptr.get());
+        } else if (auto f = dynamic_cast<const flip_face*>(h)) {
+            r.type = RTR_NODE_FLIP_FACE;
+            r.a = node(f->ptr.get());
+        } else if (auto cm = dynamic_cast<const constant_medium*>(h)) {
+            r.type = RTR_NODE_MEDIUM;
+            r.b = mat(cm->phase_function.get());
+            r.f[0] = cm->neg_inv_density;
+            r.a = node(cm->boundary.get());
+        } else if (auto s = dynamic_cast<const sphere*>(h)) {
+            r.type = RTR_NODE_SPHERE;
+            r.a = mat(s->mat_ptr.get());
+            put3(r.f, s->center);
+            r.f[3] = s->radius;
+        } else if (auto ms = dynamic_cast<const moving_sphere*>(h)) {
+            r.type = RTR_NODE_MOVING_SPHERE;
+            r.a = mat(ms->mat_ptr.get());
+            put3(r.f, ms->center0);
+            put3(r.f + 3, ms->center1);
+            r.f[6] = ms->time0;
+            r.f[7] = ms->time1;
+            r.f[8] = ms->radius;
+        } else if (auto q = dynamic_cast<const xy_rect*>(h)) {
+            r.type = RTR_NODE_XY_RECT;
+            r.a = mat(q->mp.get());
+            r.f[0] = q->x0, r.f[1] = q->x1, r.f[2] = q->y0, r.f[3] = q->y1, r.f[4] = q->k;
+        } else if (auto q2 = dynamic_cast<const xz_rect*>(h)) {
+            r.type = RTR_NODE_XZ_RECT;
+            r.a = mat(q2->mp.get());
+            r.f[0] = q2->x0, r.f[1] = q2->x1, r.f[2] = q2->z0, r.f[3] = q2->z1, r.f[4] = q2->k;
+        } else if (auto q3 = dynamic_cast<const yz_rect*>(h)) {
+            r.type = RTR_NODE_YZ_RECT;
+            r.a = mat(q3->mp.get());
+            r.f[0] = q3->y0, r.f[1] = q3->y1, r.f[2] = q3->z0, r.f[3] = q3->z1, r.f[4] = q3->k;
+        } else {
+            die("unsupported hittable class in reference scene");
+        }
+        out.nodes[ix] = r;
+        return ix;
+    }
+
+    void light(const Light* l) {
+        rtr_light r{};
+        if (auto q = dynamic_cast<const QuadLight*>(l)) {
+            r.type = RTR_LIGHT_QUAD;
+            put3(r.f, q->Q);
+            put3(r.f + 3, q->u);
+            put3(r.f + 6, q->v);
+            put3(r.f + 9, q->intensity);
+            put3(r.f + 12, q->normal);
+            r.f[15] = q->area;
+        } else {
+            die("unsupported light class in reference scene");
+        }
+        out.lights.push_back(r);
+    }
+
+    void cam(const camera& c) {
+        rtr_camera& o = out.camera;
+        put3(o.origin, c.origin);
+        put3(o.lower_left_corner, c.lower_left_corner);
+        put3(o.horizontal, c.horizontal);
+        put3(o.vertical, c.vertical);
+        put3(o.u, c.u);
+        put3(o.v, c.v);
+        put3(o.w, c.w);
+        o.lens_radius = c.lens_radius;
+        o.time0 = c.time0;
+        o.time1 = c.time1;
+    }
+};
+
+struct Loaded {
+    SceneConfig cfg;
+    shared_ptr<camera> cam;
+    int default_w = 0, default_h = 0;
+};
+
+static Loaded load_scene(int scene_id, uint32_t scene_seed) {
+    Loaded l;
+    set_rng(scene_seed);
+    l.cfg = select_scene(scene_id);
+    /* main.cpp:63-66 with RenderConfig::kShutterOpen/Close = 0/1 (main.cpp:45-46) */
+    l.cam = make_shared<camera>(l.cfg.lookfrom, l.cfg.lookat, l.cfg.vup, l.cfg.vfov, l.cfg.aspect_ratio,
+                                l.cfg.aperture, l.cfg.focus_dist, 0.0, 1.0);
+    l.default_w = l.cfg.image_width;
+    l.default_h = static_cast<int>(l.default_w / l.cfg.aspect_ratio); /* main.cpp:69 */
+    return l;
+}
+
+static int height_for(const Loaded& l, int W) { return static_cast<int>(W / l.cfg.aspect_ratio); }
+
+/* counts top-level scene.hit calls; shadow rays are the ones with a finite t_max
+ * (mis_path_integrator.h:212-213) */
+static thread_local int64_t g_closest = 0, g_shadow = 0;
+struct CountingWorld : public hittable {
+    const hittable* inner;
+    explicit CountingWorld(const hittable* h) : inner(h) {}
+    bool hit(const ray& r, double t_min, double t_max, hit_record& rec) const override {
+        if (t_max == infinity)
+            ++g_closest;
+        else
+            ++g_shadow;
+        return inner->hit(r, t_min, t_max, rec);
+    }
+    bool bounding_box(double t0, double t1, aabb& b) const override { return inner->bounding_box(t0, t1, b); }
+};
+
+static int cmd_info(int scene_id) {
+    Loaded l = load_scene(scene_id, 12345u);
+    std::printf("{\"scene\": %d, \"image_width\": %d, \"image_height\": %d, \"samples_per_pixel\": %d, "
+                "\"aspect_ratio\": %.17g, \"n_lights\": %zu}\n",
+                scene_id, l.default_w, l.default_h, l.cfg.samples_per_pixel, l.cfg.aspect_ratio,
+                l.cfg.lights.size());
+    return 0;
+}
+
+static Flattener flatten(const Loaded& l) {
+    Flattener f;
+    f.out.root = f.node(l.cfg.world.get());
+    for (const auto& li : l.cfg.lights) f.light(li.get());
+    f.cam(*l.cam);
+    f.out.background[0] = l.cfg.background.x();
+    f.out.background[1] = l.cfg.background.y();
+    f.out.background[2] = l.cfg.background.z();
+    return f;
+}
+
+static int cmd_dump_scene(int scene_id, uint32_t scene_seed, const char* path) {
+    Loaded l = load_scene(scene_id, scene_seed);
+    Flattener f = flatten(l);
+    if (!f.out.save(path)) die("cannot write scene file");
+    std::printf("{\"scene\": %d, \"nodes\": %zu, \"materials\": %zu, \"textures\": %zu, \"lights\": %zu, "
+                "\"default_width\": %d, \"default_height\": %d, \"default_spp\": %d}\n",
+                scene_id, f.out.nodes.size(), f.out.materials.size(), f.out.textures.size(), f.out.lights.size(),
+                l.default_w, l.default_h, l.cfg.samples_per_pixel);
+    return 0;
+}
+
+static int cmd_render(int scene_id, int integ, int W, int spp, uint32_t seed, uint32_t scene_seed, const char* path,
+                      int threads) {
+    Loaded l = load_scene(scene_id, scene_seed);
+    const int H = height_for(l, W);
+    auto I = make_integrator(integ);
+    CountingWorld world(l.cfg.world.get());
+    std::vector<double> img((size_t)W * H * 3, 0.0);
+    std::atomic<int> next_row(0);
+    std::atomic<int64_t> n_closest(0), n_shadow(0);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&]() {
+        g_closest = g_shadow = 0;
+        for (;;) {
+            int j = next_row.fetch_add(1);
+            if (j >= H) break;
+            for (int i = 0; i < W; ++i) {
+                color acc(0, 0, 0);
+                for (int s = 0; s < spp; ++s) {
+                    set_rng(rtr_sample_seed_inline(seed, W, i, j, s));
+                    auto u = (i + random_double()) / (W - 1);
+                    auto v = (j + random_double()) / (H - 1);
+                    ray r = l.cam->get_ray(u, v);
+                    acc += I->Li(r, world, l.cfg.background, l.cfg.lights);
+                }
+                double scale = 1.0 / spp; /* renderer.h:131 */
+                double* px = &img[((size_t)j * W + i) * 3];
+                px[0] = scale * acc.x();
+                px[1] = scale * acc.y();
+                px[2] = scale * acc.z();
+            }
+        }
+        n_closest += g_closest;
+        n_shadow += g_shadow;
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    FILE* f = std::fopen(path, "wb");
+    if (!f) die("cannot open output");
+    std::fwrite(img.data(), sizeof(double), img.size(), f);
+    std::fclose(f);
+    std::printf("{\"scene\": %d, \"integrator\": %d, \"width\": %d, \"height\": %d, \"spp\": %d, \"seed\": %u, "
+                "\"scene_seed\": %u, \"seconds\": %.6f, \"threads\": %d, \"closest_segments\": %" PRId64
+                ", \"shadow_segments\": %" PRId64 "}\n",
+                scene_id, integ, W, H, spp, seed, scene_seed, sec, threads, n_closest.load(), n_shadow.load());
+    return 0;
+}
+
+typedef rtr_li_record LiRecord;
+typedef rtr_hit_record HitRecordOut;
+typedef rtr_mat_record MatRecordOut;
+typedef rtr_light_record LightRecordOut;
+
+static int cmd_li(int scene_id, int integ, int W, int spp, uint32_t seed, uint32_t scene_seed, int n,
+                  const char* path) {
+    Loaded l = load_scene(scene_id, scene_seed);
+    const int H = height_for(l, W);
+    auto I = make_integrator(integ);
+    CountingWorld world(l.cfg.world.get());
+    std::vector<LiRecord> recs((size_t)n);
+    const uint64_t npix = (uint64_t)W * H;
+    for (int k = 0; k < n; ++k) {
+        uint64_t pix = ((uint64_t)k * 2654435761ull + 12345ull) % npix;
+        int i = (int)(pix % W), j = (int)(pix / W), s = k % spp;
+        g_closest = g_shadow = 0;
+        set_rng(rtr_sample_seed_inline(seed, W, i, j, s));
+        auto u = (i + random_double()) / (W - 1);
+        auto v = (j + random_double()) / (H - 1);
+        ray r = l.cam->get_ray(u, v);
+        color L = I->Li(r, world, l.cfg.background, l.cfg.lights);
+        LiRecord& o = recs[k];
+        o.i = i, o.j = j, o.s = s;
+        o.rng_exit = get_rng();
+        o.L[0] = L.x(), o.L[1] = L.y(), o.L[2] = L.z();
+        o.n_closest = (int32_t)g_closest;
+        o.n_shadow = (int32_t)g_shadow;
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) die("cannot open output");
+    std::fwrite(recs.data(), sizeof(LiRecord), recs.size(), f);
+    std::fclose(f);
+    std::printf("{\"scene\": %d, \"integrator\": %d, \"width\": %d, \"height\": %d, \"spp\": %d, \"n\": %d}\n",
+                scene_id, integ, W, H, spp, n);
+    return 0;
+}
+
+static vec3 gen_unit(std::mt19937_64& g) {
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    for (;;) {
+        vec3 p(U(g), U(g), U(g));
+        double l2 = p.length_squared();
+        if (l2 > 1e-6 && l2 < 1.0) return p / std::sqrt(l2);
+    }
+}
+
+static int cmd_hits(int scene_id, uint32_t scene_seed, int n, uint64_t gen_seed, const char* path) {
+    Loaded l = load_scene(scene_id, scene_seed);
+    Flattener f = flatten(l);
+    aabb wb;
+    if (!l.cfg.world->bounding_box(0, 1, wb)) die("world has no bounding box");
+    std::mt19937_64 g(gen_seed);
+    std::uniform_real_distribution<double> U01(0.0, 1.0);
+    std::vector<HitRecordOut> recs((size_t)n);
+    /* clamp the sampling volume so huge ground spheres do not dominate */
+    vec3 lo = wb.min(), hi = wb.max();
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = std::fmax(lo[c], -1200.0);
+        hi[c] = std::fmin(hi[c], 1200.0);
+    }
+    for (int k = 0; k < n; ++k) {
+        ray r;
+        double tmin = 0.001, tmax = infinity;
+        int kind = k % 4;
+        if (kind == 0) { /* camera rays */
+            set_rng(0x1234567u + 7919u * (uint32_t)k);
+            r = l.cam->get_ray(U01(g), U01(g));
+        } else {
+            vec3 o(lo.x() + (hi.x() - lo.x()) * U01(g), lo.y() + (hi.y() - lo.y()) * U01(g),
+                   lo.z() + (hi.z() - lo.z()) * U01(g));
+            vec3 d = gen_unit(g);
+            if (kind == 2) d = d * (0.25 + 4.0 * U01(g)); /* unnormalised directions (scatter fallbacks) */
+            r = ray(o, d, U01(g));
+            if (kind == 3) tmax = 50.0 + 400.0 * U01(g); /* shadow-style finite range */
+        }
+        HitRecordOut& o = recs[k];
+        std::memset(&o, 0, sizeof o);
+        Flattener::put3(o.o, r.origin());
+        Flattener::put3(o.d, r.direction());
+        o.time = r.time();
+        o.t_min = tmin;
+        o.t_max = tmax;
+        o.rng_in = 0x9E3779B9u ^ (uint32_t)(k * 2654435761u);
+        if (o.rng_in == 0) o.rng_in = 1;
+        set_rng(o.rng_in);
+        hit_record rec;
+        rec.u = rec.v = std::numeric_limits<double>::quiet_NaN();
+        rec.mat_ptr = nullptr;
+        bool h = l.cfg.world->hit(r, tmin, tmax, rec);
+        o.rng_out = get_rng();
+        o.hit = h ? 1 : 0;
+        if (h) {
+            o.front_face = rec.front_face ? 1 : 0;
+            auto it = f.mat_ix.find(rec.mat_ptr);
+            o.material = it == f.mat_ix.end() ? -1 : it->second;
+            o.t = rec.t;
+            Flattener::put3(o.p, rec.p);
+            Flattener::put3(o.n, rec.normal);
+            o.u = rec.u;
+            o.v = rec.v;
+        } else {
+            o.material = -1;
+        }
+    }
+    FILE* fo = std::fopen(path, "wb");
+    if (!fo) die("cannot open output");
+    std::fwrite(recs.data(), sizeof(HitRecordOut), recs.size(), fo);
+    std::fclose(fo);
+    std::printf("{\"scene\": %d, \"n\": %d}\n", scene_id, n);
+    return 0;
+}
+
+static int cmd_materials(int scene_id, uint32_t scene_seed, int n_per, uint64_t gen_seed, const char* path) {
+    Loaded l = load_scene(scene_id, scene_seed);
+    Flattener f = flatten(l);
+    std::mt19937_64 g(gen_seed);
+    std::uniform_real_distribution<double> U01(0.0, 1.0);
+    std::vector<MatRecordOut> recs;
+    for (size_t m = 0; m < f.mats.size(); ++m) {
+        const material* mat = f.mats[m];
+        for (int k = 0; k < n_per; ++k) {
+            MatRecordOut o;
+            std::memset(&o, 0, sizeof o);
+            o.material = (int32_t)m;
+            hit_record rec;
+            rec.normal = gen_unit(g);
+            rec.p = vec3(600 * U01(g) - 20, 600 * U01(g) - 20, 600 * U01(g) - 20);
+            rec.u = U01(g);
+            rec.v = U01(g);
+            rec.t = 1.0 + 10 * U01(g);
+            rec.front_face = (k % 3) != 0;
+            rec.mat_ptr = const_cast<material*>(mat);
+            vec3 wo = gen_unit(g);
+            if ((k % 4) != 3 && dot(wo, rec.normal) < 0) wo = -wo; /* mostly the upper hemisphere */
+            vec3 wi = gen_unit(g);
+            if ((k % 5) != 4 && dot(wi, rec.normal) < 0) wi = -wi;
+            if ((k % 7) == 6) wi = wi * (0.5 + 2 * U01(g)); /* unnormalised wi (lambertian::pdf normalises) */
+            o.front_face = rec.front_face;
+            Flattener::put3(o.p, rec.p);
+            Flattener::put3(o.n, rec.normal);
+            o.u = rec.u, o.v = rec.v;
+            Flattener::put3(o.wo, wo);
+            Flattener::put3(o.wi_in, wi);
+            o.rng_in = (uint32_t)g() | 1u;
+            set_rng(o.rng_in);
+            BSDFSample bs;
+            bs.wi = vec3(0, 0, 0);
+            bs.f = color(0, 0, 0);
+            bs.pdf = 0;
+            bs.is_specular = false;
+            bool ok = mat->sample(rec, wo, bs);
+            o.rng_out = get_rng();
+            o.sample_ok = ok;
+            o.is_specular = bs.is_specular;
+            o.is_transmission = bs.is_transmission;
+            Flattener::put3(o.s_wi, bs.wi);
+            Flattener::put3(o.s_f, bs.f);
+            o.s_pdf = bs.pdf;
+            color e = mat->eval(rec, wo, wi);
+            Flattener::put3(o.eval, e);
+            o.pdf = mat->pdf(rec, wo, wi);
+            color em = mat->emitted(rec, wo);
+            Flattener::put3(o.emitted, em);
+            recs.push_back(o);
+        }
+    }
+    FILE* fo = std::fopen(path, "wb");
+    if (!fo) die("cannot open output");
+    std::fwrite(recs.data(), sizeof(MatRecordOut), recs.size(), fo);
+    std::fclose(fo);
+    std::printf("{\"scene\": %d, \"materials\": %zu, \"n\": %zu}\n", scene_id, f.mats.size(), recs.size());
+    return 0;
+}
+
+static int cmd_lights(int scene_id, uint32_t scene_seed, int n_per, uint64_t gen_seed, const char* path) {
+    Loaded l = load_scene(scene_id, scene_seed);
+    std::mt19937_64 g(gen_seed);
+    std::uniform_real_distribution<double> U01(0.0, 1.0);
+    aabb wb;
+    l.cfg.world->bounding_box(0, 1, wb);
+    vec3 lo = wb.min(), hi = wb.max();
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = std::fmax(lo[c], -600.0);
+        hi[c] = std::fmin(hi[c], 600.0);
+    }
+    std::vector<LightRecordOut> recs;
+    for (size_t li = 0; li < l.cfg.lights.size(); ++li) {
+        const Light* L = l.cfg.lights[li].get();
+        for (int k = 0; k < n_per; ++k) {
+            LightRecordOut o;
+            std::memset(&o, 0, sizeof o);
+            o.light = (int32_t)li;
+            vec3 p(lo.x() + (hi.x() - lo.x()) * U01(g), lo.y() + (hi.y() - lo.y()) * U01(g),
+                   lo.z() + (hi.z() - lo.z()) * U01(g));
+            vec2 u(U01(g), U01(g));
+            LightSample s = L->sample(p, u);
+            /* pdf() query: half the time towards the sampled point, else random */
+            vec3 dir = (k % 2 == 0) ? s.wi * (0.5 + U01(g)) : gen_unit(g);
+            Flattener::put3(o.p, p);
+            o.u[0] = u.x(), o.u[1] = u.y();
+            Flattener::put3(o.dir, dir);
+            Flattener::put3(o.Li, s.Li);
+            Flattener::put3(o.wi, s.wi);
+            o.pdf = s.pdf;
+            o.dist = s.dist;
+            o.is_delta = s.is_delta;
+            o.pdf_dir = L->pdf(p, dir);
+            recs.push_back(o);
+        }
+    }
+    FILE* fo = std::fopen(path, "wb");
+    if (!fo) die("cannot open output");
+    std::fwrite(recs.data(), sizeof(LightRecordOut), recs.size(), fo);
+    std::fclose(fo);
+    std::printf("{\"scene\": %d, \"lights\": %zu, \"n\": %zu}\n", scene_id, l.cfg.lights.size(), recs.size());
+    return 0;
+}
+
+/* RNG known-answer vectors: for 4 seeds: 16 x random_double, then random_int(0,9) x 8,
+ * vec3::random(-1,1), vec2(r,r) as the integrator builds it, random_in_unit_disk,
+ * random_in_unit_sphere, random_unit_vector, random_cosine_direction; and the state after. */
+static int cmd_rng(const char* path) {
+    FILE* fo = std::fopen(path, "wb");
+    if (!fo) die("cannot open output");
+    const uint32_t seeds[4] = {1u, 12345u, 0x9E3779B9u, 0xFFFFFFFFu};
+    for (uint32_t sd : seeds) {
+        std::vector<double> v;
+        set_rng(sd);
+        for (int k = 0; k < 16; ++k) v.push_back(random_double());
+        for (int k = 0; k < 8; ++k) v.push_back((double)random_int(0, 9));
+        vec3 a = vec3::random(-1, 1);
+        v.push_back(a.x()), v.push_back(a.y()), v.push_back(a.z());
+        vec2 u(random_double(), random_double()); /* mis_path_integrator.h:205 */
+        v.push_back(u.x()), v.push_back(u.y());
+        vec3 d = random_in_unit_disk();
+        v.push_back(d.x()), v.push_back(d.y()), v.push_back(d.z());
+        vec3 s = random_in_unit_sphere();
+        v.push_back(s.x()), v.push_back(s.y()), v.push_back(s.z());
+        vec3 w = random_unit_vector();
+        v.push_back(w.x()), v.push_back(w.y()), v.push_back(w.z());
+        vec3 c = random_cosine_direction();
+        v.push_back(c.x()), v.push_back(c.y()), v.push_back(c.z());
+        v.push_back((double)get_rng());
+        double sdd = (double)sd;
+        std::fwrite(&sdd, 8, 1, fo);
+        std::fwrite(v.data(), 8, v.size(), fo);
+    }
+    std::fclose(fo);
+    return 0;
+}
+#endif /* !RTR_REF_UNSEEDED */
+
+#ifdef RTR_REF_WITH_RENDERER
+/* the reference's own Renderer::render, exactly as main.cpp:78-102,115 minus SDL */
+static int cmd_time(int scene_id, int integ, int W, int spp) {
+    SceneConfig cfg = select_scene(scene_id);
+    auto cam = make_shared<camera>(cfg.lookfrom, cfg.lookat, cfg.vup, cfg.vfov, cfg.aspect_ratio, cfg.aperture,
+                                   cfg.focus_dist, 0.0, 1.0);
+    int H = static_cast<int>(W / cfg.aspect_ratio);
+    RenderBuffer buf(W, H);
+    Renderer renderer;
+    renderer.set_samples(spp);
+    renderer.set_integrator(make_integrator(integ));
+    renderer.set_max_depth(50);
+    auto t0 = std::chrono::steady_clock::now();
+    renderer.render(cfg.world, cam, cfg.background, buf, cfg.lights);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double mean = 0;
+    for (const auto& row : buf.get_data())
+        for (const auto& c : row) mean += c.x() + c.y() + c.z();
+    mean /= 3.0 * W * H;
+    std::printf("{\"scene\": %d, \"integrator\": %d, \"width\": %d, \"height\": %d, \"spp\": %d, \"seconds\": %.6f, "
+                "\"msamples_per_s\": %.6f, \"threads\": %u, \"mean_gamma\": %.6f}\n",
+                scene_id, integ, W, H, spp, sec, (double)W * H * spp / sec * 1e-6,
+                std::thread::hardware_concurrency(), mean);
+    return 0;
+}
+#endif
+
+int main(int argc, char** argv) {
+    if (argc < 2) die("usage: ref_harness <command> ...");
+    std::string c = argv[1];
+    auto I = [&](int k) { return std::atoi(argv[k]); };
+    auto U = [&](int k) { return (uint32_t)std::strtoul(argv[k], nullptr, 0); };
+#ifdef RTR_REF_WITH_RENDERER
+    if (c == "time" && argc == 6) return cmd_time(I(2), I(3), I(4), I(5));
+#endif
+#ifndef RTR_REF_UNSEEDED
+    if (c == "info" && argc == 3) return cmd_info(I(2));
+    if (c == "dump-scene" && argc == 5) return cmd_dump_scene(I(2), U(3), argv[4]);
+    if (c == "render" && (argc == 9 || argc == 10))
+        return cmd_render(I(2), I(3), I(4), I(5), U(6), U(7), argv[8], argc == 10 ? I(9) : 8);
+    if (c == "li" && argc == 10) return cmd_li(I(2), I(3), I(4), I(5), U(6), U(7), I(8), argv[9]);
+    if (c == "hits" && argc == 7) return cmd_hits(I(2), U(3), I(4), std::strtoull(argv[5], nullptr, 0), argv[6]);
+    if (c == "materials" && argc == 7)
+        return cmd_materials(I(2), U(3), I(4), std::strtoull(argv[5], nullptr, 0), argv[6]);
+    if (c == "lights" && argc == 7) return cmd_lights(I(2), U(3), I(4), std::strtoull(argv[5], nullptr, 0), argv[6]);
+    if (c == "rng" && argc == 3) return cmd_rng(argv[2]);
+#endif
+    die("bad command line");
+    return 2;
+}

@@ -1,0 +1,1064 @@
+/*
+ * rt_oracle.cpp -- TEST INFRASTRUCTURE: the CPU oracle ("port") of the hot path.
+ *
+ * A plain C++ restatement of the reference's tile-threaded integrator loop that runs
+ * on the flattened scene of include/rtr_hip.h.  It is the checker the parity tests
+ * compare the HIP path with, and the `cpu_baseline` (kind "port") of bench.py.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product (ray_tracing-rendering_amd/) never does.
+ *
+ * Pinning: tests/test_oracle_golden.py checks every function below against the
+ * golden vectors in tests/golden/, which oracle/gen_golden.py produced by running
+ * the UNMODIFIED reference (oracle/_ref/ref_harness) in the build container.  The
+ * port is bit-exact to the reference on those vectors (IEEE double, same operation
+ * order, no FMA contraction: -ffp-contract=off, and libm for sin/cos/pow/log/...).
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference/src).  Expressions keep the reference's association order, e.g.
+ * `v / t` is `(1/t) * v` (core/vec3.h:208-210), and RNG draws are sequenced in the
+ * order g++ evaluates the reference's argument lists (right to left).
+ */
+#include "rtr_hip.h"
+#include "rtr_seed.h"
+#include "rtr_testrec.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr double kInf = std::numeric_limits<double>::infinity();
+constexpr double kPi = 3.1415926535897932385; /* core/rtweekend.h:18 */
+
+/* ---- core/vec3.h:12-89 ---------------------------------------------------- */
+struct V3 {
+    double x, y, z;
+};
+inline V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+inline V3 ld(const double* p) { return V3{p[0], p[1], p[2]}; }
+inline V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }                    /* vec3.h:30-32 */
+inline V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); } /* vec3.h:188-190 */
+inline V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); } /* vec3.h:192-194 */
+inline V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); } /* vec3.h:196-198 */
+inline V3 scl(double t, V3 v) { return mk(t * v.x, t * v.y, t * v.z); }   /* vec3.h:200-206 */
+inline V3 divs(V3 v, double t) { return scl(1 / t, v); }                  /* vec3.h:208-210 */
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } /* vec3.h:212-214 */
+inline V3 cross(V3 u, V3 v) {                                             /* vec3.h:216-220 */
+    return mk(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+inline double len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; } /* vec3.h:68-70 */
+inline double len(V3 a) { return std::sqrt(len2(a)); }                   /* vec3.h:64-66 */
+inline V3 unit(V3 v) { return divs(v, len(v)); }                         /* vec3.h:222-224 */
+inline bool near_zero(V3 a) {                                            /* vec3.h:81-85 */
+    const double s = 1e-8;
+    return (std::fabs(a.x) < s) && (std::fabs(a.y) < s) && (std::fabs(a.z) < s);
+}
+inline double comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+inline V3 reflect(V3 v, V3 n) { return sub(v, scl(2 * dot(v, n), n)); } /* vec3.h:239-241 */
+inline V3 refract(V3 uv, V3 n, double etai_over_etat) {                  /* vec3.h:243-248 */
+    double cos_theta = std::fmin(dot(neg(uv), n), 1.0);
+    V3 r_out_perp = scl(etai_over_etat, add(uv, scl(cos_theta, n)));
+    V3 r_out_parallel = scl(-std::sqrt(std::fabs(1.0 - len2(r_out_perp))), n);
+    return add(r_out_perp, r_out_parallel);
+}
+inline double clampd(double x, double lo, double hi) { /* rtweekend.h:40-46 */
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+
+/* ---- core/rtweekend.h:24-50: xorshift32 ------------------------------------ */
+struct Rng {
+    uint32_t s;
+    inline double next() { /* rtweekend.h:24-34 */
+        s ^= s << 13;
+        s ^= s >> 17;
+        s ^= s << 5;
+        return s * 2.3283064365386963e-10;
+    }
+    inline double range(double lo, double hi) { return lo + (hi - lo) * next(); } /* :36-38 */
+    inline int irange(int lo, int hi) { return static_cast<int>(range(lo, hi + 1)); } /* :48-50 */
+};
+
+/* vec3::random(min,max) (vec3.h:76-79): g++ evaluates the three arguments right to
+ * left, so z takes the first draw (pinned by tests/golden/rng.bin). */
+inline V3 rand_vec(Rng& g, double lo, double hi) {
+    double z = g.range(lo, hi);
+    double y = g.range(lo, hi);
+    double x = g.range(lo, hi);
+    return mk(x, y, z);
+}
+inline V3 random_in_unit_sphere(Rng& g) { /* vec3.h:226-233 */
+    for (;;) {
+        V3 p = rand_vec(g, -1, 1);
+        if (len2(p) >= 1) continue;
+        return p;
+    }
+}
+inline V3 random_unit_vector(Rng& g) { return unit(random_in_unit_sphere(g)); } /* vec3.h:235-237 */
+inline V3 random_in_unit_disk(Rng& g) { /* vec3.h:250-257; y drawn first (g++ order) */
+    for (;;) {
+        double y = g.range(-1, 1);
+        double x = g.range(-1, 1);
+        V3 p = mk(x, y, 0);
+        if (len2(p) >= 1) continue;
+        return p;
+    }
+}
+inline V3 random_cosine_direction(Rng& g) { /* vec3.h:261-269 */
+    double r1 = g.next();
+    double r2 = g.next();
+    double z = std::sqrt(1 - r2);
+    double phi = 2 * kPi * r1;
+    double x = std::cos(phi) * std::sqrt(r2);
+    double y = std::sin(phi) * std::sqrt(r2);
+    return mk(x, y, z);
+}
+
+/* ---- core/ray.h:6-44 -------------------------------------------------------- */
+struct Ray {
+    V3 o, d, inv;
+    int sign[3];
+    double tm;
+};
+inline Ray make_ray(V3 o, V3 d, double tm) { /* ray.h:9-17 */
+    Ray r;
+    r.o = o;
+    r.d = d;
+    r.tm = tm;
+    r.inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    r.sign[0] = (r.inv.x < 0);
+    r.sign[1] = (r.inv.y < 0);
+    r.sign[2] = (r.inv.z < 0);
+    return r;
+}
+inline V3 ray_at(const Ray& r, double t) { return add(r.o, scl(t, r.d)); } /* ray.h:35-37 */
+
+/* ---- core/onb.h:24-37 -------------------------------------------------------- */
+struct Onb {
+    V3 u, v, w;
+};
+inline Onb onb_from_w(V3 n) { /* onb.h:32-37 */
+    Onb b;
+    b.w = unit(n);
+    V3 a = (std::fabs(b.w.x) > 0.9) ? mk(0, 1, 0) : mk(1, 0, 0);
+    b.v = unit(cross(b.w, a));
+    b.u = cross(b.w, b.v);
+    return b;
+}
+inline V3 onb_local(const Onb& b, V3 a) { /* onb.h:28-30 */
+    return add(add(scl(a.x, b.u), scl(a.y, b.v)), scl(a.z, b.w));
+}
+
+/* ---- geometry/hittable.h:10-23 ----------------------------------------------- */
+struct Rec {
+    V3 p, normal;
+    int mat;
+    double t, u, v;
+    bool front_face;
+};
+inline void set_face_normal(Rec& rec, const Ray& r, V3 outward) { /* hittable.h:19-22 */
+    rec.front_face = dot(r.d, outward) < 0;
+    rec.normal = rec.front_face ? outward : neg(outward);
+}
+
+struct Scene {
+    const rtr_scene_desc* d;
+};
+
+/* ---- geometry/aabb.h:31-48 ---------------------------------------------------- */
+inline bool aabb_hit(const double* b, const Ray& r, double t_min, double t_max) {
+    for (int a = 0; a < 3; ++a) {
+        double t0 = (b[a] - comp(r.o, a)) * comp(r.inv, a);
+        double t1 = (b[3 + a] - comp(r.o, a)) * comp(r.inv, a);
+        if (r.sign[a]) std::swap(t0, t1);
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+bool hit_node(const Scene& sc, int ix, const Ray& r, double t_min, double t_max, Rec& rec, Rng& g);
+
+/* geometry/sphere.h:24-30 */
+inline void sphere_uv(V3 p, double& u, double& v) {
+    double theta = std::acos(-p.y);
+    double phi = std::atan2(-p.z, p.x) + kPi;
+    u = phi / (2 * kPi);
+    v = theta / kPi;
+}
+
+/* geometry/sphere.h:33-60 and geometry/moving_sphere.h:32-62 */
+inline bool sphere_hit(const rtr_node& n, bool moving, const Ray& r, double t_min, double t_max, Rec& rec) {
+    V3 center;
+    double radius;
+    if (!moving) {
+        center = ld(n.f);
+        radius = n.f[3];
+    } else { /* moving_sphere::center(time), moving_sphere.h:32-34 */
+        V3 c0 = ld(n.f), c1 = ld(n.f + 3);
+        double t0 = n.f[6], t1 = n.f[7];
+        center = add(c0, scl((r.tm - t0) / (t1 - t0), sub(c1, c0)));
+        radius = n.f[8];
+    }
+    V3 oc = sub(r.o, center);
+    double a = len2(r.d);
+    double half_b = dot(oc, r.d);
+    double c = len2(oc) - radius * radius;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return false;
+    double sqrtd = std::sqrt(discriminant);
+    double root = (-half_b - sqrtd) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    rec.t = root;
+    rec.p = ray_at(r, rec.t);
+    V3 outward = divs(sub(rec.p, center), radius);
+    set_face_normal(rec, r, outward);
+    if (!moving) sphere_uv(outward, rec.u, rec.v); /* moving_sphere leaves u,v untouched */
+    rec.mat = n.a;
+    return true;
+}
+
+/* geometry/aarect.h:79-135: axis k is the constant axis, (a,b) the in-plane axes */
+inline bool rect_hit(const rtr_node& n, int ka, int aa, int ba, const Ray& r, double t_min, double t_max,
+                     Rec& rec) {
+    double k = n.f[4];
+    double t = (k - comp(r.o, ka)) / comp(r.d, ka);
+    if (t < t_min || t > t_max) return false;
+    double a = comp(r.o, aa) + t * comp(r.d, aa);
+    double b = comp(r.o, ba) + t * comp(r.d, ba);
+    if (a < n.f[0] || a > n.f[1] || b < n.f[2] || b > n.f[3]) return false;
+    rec.u = (a - n.f[0]) / (n.f[1] - n.f[0]);
+    rec.v = (b - n.f[2]) / (n.f[3] - n.f[2]);
+    rec.t = t;
+    V3 outward = mk(ka == 0 ? 1 : 0, ka == 1 ? 1 : 0, ka == 2 ? 1 : 0);
+    set_face_normal(rec, r, outward);
+    rec.mat = n.a;
+    rec.p = ray_at(r, t);
+    return true;
+}
+
+/* geometry/constant_medium.h:55-104 */
+inline bool medium_hit(const Scene& sc, const rtr_node& n, const Ray& r, double t_min, double t_max, Rec& rec,
+                       Rng& g) {
+    Rec rec1, rec2;
+    rec1.u = rec1.v = rec2.u = rec2.v = 0;
+    if (!hit_node(sc, n.a, r, -kInf, kInf, rec1, g)) return false;
+    if (!hit_node(sc, n.a, r, rec1.t + 0.0001, kInf, rec2, g)) return false;
+    if (rec1.t < t_min) rec1.t = t_min;
+    if (rec2.t > t_max) rec2.t = t_max;
+    if (rec1.t >= rec2.t) return false;
+    if (rec1.t < 0) rec1.t = 0;
+    const double ray_length = len(r.d);
+    const double distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
+    const double hit_distance = n.f[0] * std::log(g.next());
+    if (hit_distance > distance_inside_boundary) return false;
+    rec.t = rec1.t + hit_distance / ray_length;
+    rec.p = ray_at(r, rec.t);
+    rec.normal = mk(1, 0, 0);
+    rec.front_face = true;
+    rec.mat = n.b;
+    return true;
+}
+
+bool hit_node(const Scene& sc, int ix, const Ray& r, double t_min, double t_max, Rec& rec, Rng& g) {
+    const rtr_node& n = sc.d->nodes[ix];
+    switch (n.type) {
+    case RTR_NODE_BVH: { /* geometry/bvh.h:40-50 */
+        if (!aabb_hit(n.f, r, t_min, t_max)) return false;
+        bool hit_left = hit_node(sc, n.a, r, t_min, t_max, rec, g);
+        bool hit_right = hit_node(sc, n.b, r, t_min, hit_left ? rec.t : t_max, rec, g);
+        return hit_left || hit_right;
+    }
+    case RTR_NODE_LIST: { /* geometry/hittable_list.h:33-47 */
+        Rec temp;
+        temp.u = temp.v = std::numeric_limits<double>::quiet_NaN();
+        bool hit_anything = false;
+        double closest = t_max;
+        for (int k = 0; k < n.b; ++k) {
+            if (hit_node(sc, sc.d->list_children[n.a + k], r, t_min, closest, temp, g)) {
+                hit_anything = true;
+                closest = temp.t;
+                rec = temp;
+            }
+        }
+        return hit_anything;
+    }
+    case RTR_NODE_TRANSLATE: { /* geometry/hittable.h:51-62 */
+        V3 off = ld(n.f);
+        Ray moved = make_ray(sub(r.o, off), r.d, r.tm);
+        if (!hit_node(sc, n.a, moved, t_min, t_max, rec, g)) return false;
+        rec.p = add(rec.p, off);
+        set_face_normal(rec, moved, rec.normal);
+        return true;
+    }
+    case RTR_NODE_ROTATE_Y: { /* geometry/hittable.h:127-156 */
+        double s = n.f[0], c = n.f[1];
+        V3 o = r.o, d = r.d;
+        o.x = c * r.o.x - s * r.o.z;
+        o.z = s * r.o.x + c * r.o.z;
+        d.x = c * r.d.x - s * r.d.z;
+        d.z = s * r.d.x + c * r.d.z;
+        Ray rot = make_ray(o, d, r.tm);
+        if (!hit_node(sc, n.a, rot, t_min, t_max, rec, g)) return false;
+        V3 p = rec.p, nn = rec.normal;
+        p.x = c * rec.p.x + s * rec.p.z;
+        p.z = -s * rec.p.x + c * rec.p.z;
+        nn.x = c * rec.normal.x + s * rec.normal.z;
+        nn.z = -s * rec.normal.x + c * rec.normal.z;
+        rec.p = p;
+        set_face_normal(rec, rot, nn);
+        return true;
+    }
+    case RTR_NODE_FLIP_FACE: /* geometry/hittable.h:163-170 */
+        if (!hit_node(sc, n.a, r, t_min, t_max, rec, g)) return false;
+        rec.front_face = !rec.front_face;
+        return true;
+    case RTR_NODE_MEDIUM: return medium_hit(sc, n, r, t_min, t_max, rec, g);
+    case RTR_NODE_SPHERE: return sphere_hit(n, false, r, t_min, t_max, rec);
+    case RTR_NODE_MOVING_SPHERE: return sphere_hit(n, true, r, t_min, t_max, rec);
+    case RTR_NODE_XY_RECT: return rect_hit(n, 2, 0, 1, r, t_min, t_max, rec);
+    case RTR_NODE_XZ_RECT: return rect_hit(n, 1, 0, 2, r, t_min, t_max, rec);
+    case RTR_NODE_YZ_RECT: return rect_hit(n, 0, 1, 2, r, t_min, t_max, rec);
+    default: return false;
+    }
+}
+
+/* ---- materials/perlin.h:21-111 ------------------------------------------------- */
+inline double perlin_noise(const rtr_perlin& pn, V3 p) { /* perlin.h:21-39,95-111 */
+    double u = p.x - std::floor(p.x);
+    double v = p.y - std::floor(p.y);
+    double w = p.z - std::floor(p.z);
+    int i = static_cast<int>(std::floor(p.x));
+    int j = static_cast<int>(std::floor(p.y));
+    int k = static_cast<int>(std::floor(p.z));
+    V3 c[2][2][2];
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++)
+                c[di][dj][dk] =
+                    ld(pn.ranvec[pn.perm_x[(i + di) & 255] ^ pn.perm_y[(j + dj) & 255] ^ pn.perm_z[(k + dk) & 255]]);
+    double uu = u * u * (3 - 2 * u);
+    double vv = v * v * (3 - 2 * v);
+    double ww = w * w * (3 - 2 * w);
+    double accum = 0.0;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++)
+            for (int cc = 0; cc < 2; cc++) {
+                V3 weight_v = mk(u - a, v - b, w - cc);
+                accum += (a * uu + (1 - a) * (1 - uu)) * (b * vv + (1 - b) * (1 - vv)) *
+                         (cc * ww + (1 - cc) * (1 - ww)) * dot(c[a][b][cc], weight_v);
+            }
+    return accum;
+}
+inline double perlin_turb(const rtr_perlin& pn, V3 p) { /* perlin.h:41-54, depth 7 */
+    double accum = 0.0;
+    V3 temp_p = p;
+    double weight = 1.0;
+    for (int i = 0; i < 7; i++) {
+        accum += weight * perlin_noise(pn, temp_p);
+        weight *= 0.5;
+        temp_p = mk(temp_p.x * 2, temp_p.y * 2, temp_p.z * 2);
+    }
+    return std::fabs(accum);
+}
+
+/* ---- materials/texture.h:11-162 -------------------------------------------------- */
+V3 tex_value(const Scene& sc, int ix, double u, double v, V3 p) {
+    const rtr_texture& t = sc.d->textures[ix];
+    switch (t.type) {
+    case RTR_TEX_SOLID: return ld(t.f); /* texture.h:46-48 */
+    case RTR_TEX_CHECKER: {             /* texture.h:68-75 */
+        double sines = std::sin(10 * p.x) * std::sin(10 * p.y) * std::sin(10 * p.z);
+        return sines < 0 ? tex_value(sc, t.b, u, v, p) : tex_value(sc, t.a, u, v, p);
+    }
+    case RTR_TEX_NOISE: { /* texture.h:155-158 */
+        double x = 1 + std::sin(t.f[0] * p.z + 10 * perlin_turb(sc.d->perlin[t.a], p));
+        return scl(x, scl(0.5, mk(1, 1, 1)));
+    }
+    case RTR_TEX_IMAGE: { /* texture.h:115-139 */
+        if (t.a < 0) return mk(0, 1, 1);
+        const rtr_image& im = sc.d->images[t.a];
+        u = clampd(u, 0.0, 1.0);
+        v = 1.0 - clampd(v, 0.0, 1.0);
+        int i = static_cast<int>(u * im.width);
+        int j = static_cast<int>(v * im.height);
+        if (i >= im.width) i = im.width - 1;
+        if (j >= im.height) j = im.height - 1;
+        const double color_scale = 1.0 / 255.0;
+        const uint8_t* px = sc.d->image_bytes + im.offset + (size_t)j * 3 * im.width + (size_t)i * 3;
+        return mk(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
+    }
+    default: return mk(0, 0, 0);
+    }
+}
+inline double tex_scalar(const Scene& sc, int ix, double u, double v, V3 p) { /* texture.h:15-17 */
+    return tex_value(sc, ix, u, v, p).x;
+}
+inline V3 tex_normal(const Scene& sc, int ix, double u, double v, V3 p) { /* texture.h:19-22 */
+    V3 c = tex_value(sc, ix, u, v, p);
+    return unit(sub(scl(2.0, c), mk(1, 1, 1)));
+}
+
+/* ---- materials/material.h ----------------------------------------------------------- */
+struct BSDFSample { /* material.h:13-20 */
+    V3 wi, f;
+    double pdf;
+    bool is_specular;
+    bool is_transmission = false;
+};
+
+/* PBRMaterial helpers, material.h:398-432 */
+inline double distribution_ggx(V3 N, V3 H, double roughness) {
+    double a = roughness * roughness;
+    double a2 = a * a;
+    double NdotH = std::max(dot(N, H), 0.0);
+    double NdotH2 = NdotH * NdotH;
+    double nom = a2;
+    double denom = (NdotH2 * (a2 - 1.0) + 1.0);
+    denom = kPi * denom * denom;
+    return nom / denom;
+}
+inline double geometry_schlick_ggx(double NdotV, double roughness) {
+    double a = roughness;
+    double k = (a * a) / 2.0;
+    double nom = NdotV;
+    double denom = NdotV * (1.0 - k) + k;
+    return nom / denom;
+}
+inline double geometry_smith(V3 N, V3 V, V3 L, double roughness) {
+    double NdotV = std::max(dot(N, V), 0.0);
+    double NdotL = std::max(dot(N, L), 0.0);
+    double ggx2 = geometry_schlick_ggx(NdotV, roughness);
+    double ggx1 = geometry_schlick_ggx(NdotL, roughness);
+    return ggx1 * ggx2;
+}
+inline V3 fresnel_schlick(double cosTheta, V3 F0) {
+    return add(F0, scl(std::pow(1.0 - cosTheta, 5.0), sub(mk(1, 1, 1), F0)));
+}
+/* the normal-mapped shading normal shared by PBR sample/pdf/eval, material.h:247-261 */
+inline V3 pbr_normal(const Scene& sc, const rtr_material& m, const Rec& rec) {
+    V3 N = rec.normal;
+    if (m.tex[3] >= 0) {
+        V3 ax0, ax1, ax2 = N;
+        if (std::fabs(N.y) > 0.999)
+            ax0 = mk(1, 0, 0);
+        else
+            ax0 = unit(cross(N, mk(0, 1, 0)));
+        ax1 = cross(N, ax0);
+        V3 ln = tex_normal(sc, m.tex[3], rec.u, rec.v, rec.p);
+        N = unit(add(add(scl(ln.x, ax0), scl(ln.y, ax1)), scl(ln.z, ax2)));
+    }
+    return N;
+}
+double pbr_pdf(const Scene& sc, const rtr_material& m, const Rec& rec, V3 wo, V3 wi) { /* material.h:305-340 */
+    V3 N = pbr_normal(sc, m, rec);
+    if (dot(N, wi) <= 0) return 0;
+    double rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
+    rough = clampd(rough, 0.01, 1.0);
+    double pdf_diff = dot(N, wi) / kPi;
+    V3 H = unit(add(wo, wi));
+    double D = distribution_ggx(N, H, rough);
+    double NdotH = std::max(dot(N, H), 0.0);
+    double HdotV = std::max(dot(H, wo), 0.0);
+    double pdf_spec = (D * NdotH) / (4.0 * HdotV + 0.0001);
+    return 0.5 * pdf_diff + 0.5 * pdf_spec;
+}
+V3 pbr_eval(const Scene& sc, const rtr_material& m, const Rec& rec, V3 wo, V3 wi) { /* material.h:342-396 */
+    V3 N = pbr_normal(sc, m, rec);
+    double NdotL = dot(N, wi);
+    double NdotV = dot(N, wo);
+    if (NdotL <= 0 || NdotV <= 0) return mk(0, 0, 0);
+    double rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
+    double metal = tex_scalar(sc, m.tex[2], rec.u, rec.v, rec.p);
+    V3 base_color = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    rough = clampd(rough, 0.01, 1.0);
+    V3 H = unit(add(wo, wi));
+    V3 F0 = mk(0.04, 0.04, 0.04);
+    V3 metal_vec = mk(metal, metal, metal);
+    F0 = add(mul(sub(mk(1.0, 1.0, 1.0), metal_vec), F0), mul(metal_vec, base_color));
+    V3 F = fresnel_schlick(std::max(dot(H, wo), 0.0), F0);
+    double D = distribution_ggx(N, H, rough);
+    double G = geometry_smith(N, wo, wi, rough);
+    V3 numerator = scl(D * G, F);
+    double denominator = 4.0 * NdotV * NdotL + 0.0001;
+    V3 specular = divs(numerator, denominator);
+    V3 kS = F;
+    V3 kD = sub(mk(1.0, 1.0, 1.0), kS);
+    kD = scl(1.0 - metal, kD);
+    V3 diffuse = divs(mul(kD, base_color), kPi);
+    return add(diffuse, specular);
+}
+
+/* dielectric::reflectance, material.h:199-203 */
+inline double reflectance(double cosine, double ref_idx) {
+    double r0 = (1 - ref_idx) / (1 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1 - r0) * std::pow((1 - cosine), 5);
+}
+
+/* material::emitted(rec, wo): material.h:32-34 (base), :222-227 (diffuse_light) */
+V3 mat_emitted(const Scene& sc, const Rec& rec) {
+    const rtr_material& m = sc.d->materials[rec.mat];
+    if (m.type == RTR_MAT_DIFFUSE_LIGHT && rec.front_face) return tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    return mk(0, 0, 0);
+}
+/* material::emitted(u,v,p): material.h:27-29 (base), :218-220 (diffuse_light, two-sided) */
+V3 mat_emitted_legacy(const Scene& sc, const Rec& rec) {
+    const rtr_material& m = sc.d->materials[rec.mat];
+    if (m.type == RTR_MAT_DIFFUSE_LIGHT) return tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    return mk(0, 0, 0);
+}
+
+/* material::sample */
+bool mat_sample(const Scene& sc, const Rec& rec, V3 wo, BSDFSample& s, Rng& g) {
+    const rtr_material& m = sc.d->materials[rec.mat];
+    switch (m.type) {
+    case RTR_MAT_LAMBERTIAN: { /* material.h:79-90 */
+        V3 scatter_direction = add(rec.normal, random_unit_vector(g));
+        if (near_zero(scatter_direction)) scatter_direction = rec.normal;
+        s.wi = unit(scatter_direction);
+        s.pdf = dot(rec.normal, s.wi) / kPi;
+        s.f = divs(tex_value(sc, m.tex[0], rec.u, rec.v, rec.p), kPi);
+        s.is_specular = false;
+        return true;
+    }
+    case RTR_MAT_METAL: { /* material.h:123-131 */
+        V3 reflected = reflect(unit(neg(wo)), rec.normal);
+        s.wi = unit(add(reflected, scl(m.f[3], random_in_unit_sphere(g))));
+        s.f = ld(m.f);
+        s.pdf = 1.0;
+        s.is_specular = true;
+        return dot(s.wi, rec.normal) > 0;
+    }
+    case RTR_MAT_DIELECTRIC: { /* material.h:152-174 */
+        s.f = mk(1.0, 1.0, 1.0);
+        s.is_specular = true;
+        s.pdf = 1.0;
+        double ir = m.f[0];
+        double refraction_ratio = rec.front_face ? (1.0 / ir) : ir;
+        V3 unit_direction = neg(wo);
+        double cos_theta = std::fmin(dot(neg(unit_direction), rec.normal), 1.0);
+        double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > g.next()) {
+            s.wi = reflect(unit_direction, rec.normal);
+            s.is_transmission = false;
+        } else {
+            s.wi = refract(unit_direction, rec.normal, refraction_ratio);
+            s.is_transmission = true;
+        }
+        return true;
+    }
+    case RTR_MAT_PBR: { /* material.h:245-303 */
+        V3 N = pbr_normal(sc, m, rec);
+        double rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
+        rough = clampd(rough, 0.01, 1.0);
+        if (g.next() < 0.5) {
+            Onb uvw = onb_from_w(N);
+            double r1 = g.next();
+            double r2 = g.next();
+            double a = rough * rough;
+            double phi = 2.0 * kPi * r1;
+            double cos_theta = std::sqrt((1.0 - r2) / (1.0 + (a * a - 1.0) * r2));
+            double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
+            V3 H_local = mk(sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta);
+            V3 H = onb_local(uvw, H_local);
+            V3 L = reflect(neg(wo), H);
+            if (dot(N, L) <= 0) return false;
+            s.wi = L;
+        } else {
+            Onb uvw = onb_from_w(N);
+            V3 L = onb_local(uvw, random_cosine_direction(g));
+            if (dot(N, L) <= 0) L = N;
+            s.wi = unit(L);
+        }
+        s.is_specular = false;
+        s.pdf = pbr_pdf(sc, m, rec, wo, s.wi);
+        s.f = pbr_eval(sc, m, rec, wo, s.wi);
+        if (s.pdf < 1e-6) return false;
+        return true;
+    }
+    default: return false; /* diffuse_light (material.h:213-216), isotropic (base, :42-45) */
+    }
+}
+
+/* material::eval, material.h:48-51 (base 0), :98-101 (lambertian: no hemisphere test), :342 (PBR) */
+V3 mat_eval(const Scene& sc, const Rec& rec, V3 wo, V3 wi) {
+    const rtr_material& m = sc.d->materials[rec.mat];
+    if (m.type == RTR_MAT_LAMBERTIAN) return divs(tex_value(sc, m.tex[0], rec.u, rec.v, rec.p), kPi);
+    if (m.type == RTR_MAT_PBR) return pbr_eval(sc, m, rec, wo, wi);
+    return mk(0, 0, 0);
+}
+/* material::pdf, material.h:54-57 (base 0), :92-96 (lambertian), :305 (PBR) */
+double mat_pdf(const Scene& sc, const Rec& rec, V3 wo, V3 wi) {
+    const rtr_material& m = sc.d->materials[rec.mat];
+    if (m.type == RTR_MAT_LAMBERTIAN) {
+        double cosine = dot(rec.normal, unit(wi));
+        return cosine < 0 ? 0 : cosine / kPi;
+    }
+    if (m.type == RTR_MAT_PBR) return pbr_pdf(sc, m, rec, wo, wi);
+    return 0.0;
+}
+/* legacy material::scatter(r_in, rec, attenuation, scattered) */
+bool mat_scatter(const Scene& sc, const Ray& r_in, const Rec& rec, V3& attenuation, Ray& scattered, Rng& g) {
+    const rtr_material& m = sc.d->materials[rec.mat];
+    switch (m.type) {
+    case RTR_MAT_LAMBERTIAN: { /* material.h:103-112 */
+        V3 scatter_direction = add(rec.normal, random_unit_vector(g));
+        if (near_zero(scatter_direction)) scatter_direction = rec.normal;
+        scattered = make_ray(rec.p, scatter_direction, r_in.tm);
+        attenuation = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+        return true;
+    }
+    case RTR_MAT_METAL: { /* material.h:133-140 */
+        V3 reflected = reflect(unit(r_in.d), rec.normal);
+        scattered = make_ray(rec.p, add(reflected, scl(m.f[3], random_in_unit_sphere(g))), r_in.tm);
+        attenuation = ld(m.f);
+        return dot(scattered.d, rec.normal) > 0;
+    }
+    case RTR_MAT_DIELECTRIC: { /* material.h:176-193 */
+        attenuation = mk(1.0, 1.0, 1.0);
+        double ir = m.f[0];
+        double refraction_ratio = rec.front_face ? (1.0 / ir) : ir;
+        V3 unit_direction = unit(r_in.d);
+        double cos_theta = std::fmin(dot(neg(unit_direction), rec.normal), 1.0);
+        double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        V3 direction;
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > g.next())
+            direction = reflect(unit_direction, rec.normal);
+        else
+            direction = refract(unit_direction, rec.normal, refraction_ratio);
+        scattered = make_ray(rec.p, direction, r_in.tm);
+        return true;
+    }
+    case RTR_MAT_ISOTROPIC: { /* constant_medium.h:19-24 */
+        scattered = make_ray(rec.p, random_in_unit_sphere(g), r_in.tm);
+        attenuation = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+        return true;
+    }
+    default: return false; /* diffuse_light (material.h:229-232), PBRMaterial (base, :66-69) */
+    }
+}
+
+/* ---- lighting/light.h:7-13, lighting/quad_light.h:18-77 ------------------------------ */
+struct LightSample {
+    V3 Li, wi;
+    double pdf, dist;
+    bool is_delta;
+};
+LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy) { /* quad_light.h:18-48 */
+    LightSample s;
+    V3 Q = ld(l.f), U = ld(l.f + 3), Vv = ld(l.f + 6), normal = ld(l.f + 12);
+    double area = l.f[15];
+    V3 light_point = add(add(Q, scl(ux, U)), scl(uy, Vv));
+    V3 d = sub(light_point, p);
+    double dist_sq = len2(d);
+    s.dist = std::sqrt(dist_sq);
+    s.wi = divs(d, s.dist);
+    s.is_delta = false;
+    double cos_theta = dot(neg(s.wi), normal);
+    if (cos_theta <= 0) {
+        s.Li = mk(0, 0, 0);
+        s.pdf = 0;
+        return s;
+    }
+    s.Li = ld(l.f + 9);
+    s.pdf = dist_sq / (area * cos_theta);
+    return s;
+}
+double light_pdf(const rtr_light& l, V3 origin, V3 direction) { /* quad_light.h:50-77 */
+    V3 Q = ld(l.f), U = ld(l.f + 3), Vv = ld(l.f + 6), normal = ld(l.f + 12);
+    double area = l.f[15];
+    double denom = dot(direction, normal);
+    if (denom >= -1e-6) return 0;
+    double t = dot(sub(Q, origin), normal) / denom;
+    if (t < 0.001 || t > kInf) return 0;
+    V3 intersection = add(origin, scl(t, direction));
+    V3 planar = sub(intersection, Q);
+    double alpha = dot(planar, U) / len2(U);
+    double beta = dot(planar, Vv) / len2(Vv);
+    if (alpha < 0 || alpha > 1 || beta < 0 || beta > 1) return 0;
+    double dist_sq = t * t * len2(direction);
+    double cos_theta = -denom / len(direction);
+    return dist_sq / (area * cos_theta);
+}
+
+/* ---- renderer/camera.h:32-40 ---------------------------------------------------------- */
+Ray camera_get_ray(const rtr_camera& c, double s, double t, Rng& g) {
+    V3 rd = scl(c.lens_radius, random_in_unit_disk(g));
+    V3 offset = add(scl(rd.x, ld(c.u)), scl(rd.y, ld(c.v)));
+    V3 origin = ld(c.origin);
+    V3 dir = sub(sub(add(add(ld(c.lower_left_corner), scl(s, ld(c.horizontal))), scl(t, ld(c.vertical))), origin),
+                 offset);
+    double tm = g.range(c.time0, c.time1);
+    return make_ray(add(origin, offset), dir, tm);
+}
+
+/* ---- renderer/mis_path_integrator.h ----------------------------------------------------- */
+inline V3 clamp_radiance(V3 L, double max_value = 100.0) { /* :154-162 */
+    if (L.x > max_value || L.y > max_value || L.z > max_value) {
+        double max_c = std::max({L.x, L.y, L.z});
+        if (max_c > max_value) return scl(max_value / max_c, L);
+    }
+    return L;
+}
+inline double power_heuristic(double pdf_a, double pdf_b) { /* :165-170 */
+    double a2 = pdf_a * pdf_a;
+    double b2 = pdf_b * pdf_b;
+    double denom = a2 + b2;
+    return denom > 0 ? a2 / denom : 0.0;
+}
+
+struct Counters {
+    int64_t closest = 0, shadow = 0;
+};
+
+double compute_light_pdf(const Scene& sc, const Ray& current_ray) { /* :173-188 */
+    double total_pdf = 0.0;
+    double light_select_pdf = 1.0 / sc.d->n_lights;
+    for (int k = 0; k < sc.d->n_lights; ++k)
+        total_pdf += light_pdf(sc.d->lights[k], current_ray.o, current_ray.d) * light_select_pdf;
+    return total_pdf;
+}
+
+V3 sample_lights_mis(const Scene& sc, const Rec& rec, V3 wo, Rng& g, Counters& cnt) { /* :191-234 */
+    const int n_lights = sc.d->n_lights;
+    if (n_lights == 0) return mk(0, 0, 0);
+    V3 L_direct = mk(0, 0, 0);
+    int light_idx = g.irange(0, n_lights - 1);
+    const rtr_light& light = sc.d->lights[light_idx];
+    double light_select_pdf = 1.0 / n_lights;
+    /* vec2 u(random_double(), random_double()): u.y takes the first draw (g++ order) */
+    double uy = g.next();
+    double ux = g.next();
+    LightSample ls = light_sample(light, rec.p, ux, uy);
+    if (ls.pdf > 0 && len2(ls.Li) > 0) {
+        Ray shadow_ray = make_ray(rec.p, ls.wi, 0);
+        Rec shadow_rec;
+        ++cnt.shadow;
+        bool in_shadow = hit_node(sc, sc.d->root, shadow_ray, 0.001, ls.dist - 0.001, shadow_rec, g);
+        if (!in_shadow) {
+            V3 f = mat_eval(sc, rec, wo, ls.wi);
+            double cos_theta = std::abs(dot(ls.wi, rec.normal));
+            if (ls.is_delta) {
+                L_direct = add(L_direct, divs(scl(cos_theta, mul(f, ls.Li)), light_select_pdf));
+            } else {
+                double bsdf_pdf = mat_pdf(sc, rec, wo, ls.wi);
+                double lpdf = ls.pdf * light_select_pdf;
+                double mis_weight = power_heuristic(lpdf, bsdf_pdf);
+                L_direct = add(L_direct, divs(scl(mis_weight, scl(cos_theta, mul(f, ls.Li))), lpdf));
+            }
+        }
+    }
+    return L_direct;
+}
+
+V3 li_mis(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g, Counters& cnt) { /* :25-150 */
+    V3 throughput = mk(1.0, 1.0, 1.0);
+    V3 L = mk(0.0, 0.0, 0.0);
+    Ray current_ray = r;
+    bool specular_bounce = false;
+    double prev_bsdf_pdf = 0.0;
+    const bool have_lights = sc.d->n_lights > 0;
+    const V3 background = ld(sc.d->background);
+    for (int depth = 0; depth < max_depth; ++depth) {
+        Rec rec;
+        rec.u = rec.v = 0;
+        ++cnt.closest;
+        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) {
+            /* no infinite light type is flattened, so found_env is false (:41-50) */
+            L = add(L, mul(throughput, background));
+            break;
+        }
+        V3 wo = neg(unit(current_ray.d));
+        V3 emitted = mat_emitted(sc, rec);
+        if (len2(emitted) > 0) {
+            V3 L_emit;
+            if (depth == 0 || specular_bounce) {
+                L_emit = mul(throughput, emitted);
+            } else if (have_lights) {
+                double lpdf = compute_light_pdf(sc, current_ray);
+                double mis_weight = power_heuristic(prev_bsdf_pdf, lpdf);
+                L_emit = scl(mis_weight, mul(throughput, emitted));
+            } else {
+                L_emit = mul(throughput, emitted);
+            }
+            if (depth == 0)
+                L = add(L, L_emit);
+            else
+                L = add(L, clamp_radiance(L_emit));
+        }
+        specular_bounce = false; /* material::is_specular() is never overridden */
+        if (!specular_bounce && have_lights) {
+            V3 L_direct = mul(throughput, sample_lights_mis(sc, rec, wo, g, cnt));
+            L = add(L, clamp_radiance(L_direct));
+        }
+        BSDFSample bs;
+        if (!mat_sample(sc, rec, wo, bs, g)) {
+            Ray scattered;
+            V3 attenuation;
+            if (!mat_scatter(sc, current_ray, rec, attenuation, scattered, g)) break;
+            throughput = mul(throughput, attenuation);
+            current_ray = scattered;
+            specular_bounce = false;
+            prev_bsdf_pdf = 0.0;
+        } else {
+            if (bs.pdf < 1e-8 && !bs.is_specular) break;
+            specular_bounce = bs.is_specular;
+            prev_bsdf_pdf = bs.is_specular ? 0.0 : bs.pdf;
+            double cos_theta = std::abs(dot(bs.wi, rec.normal));
+            if (bs.is_specular)
+                throughput = mul(throughput, bs.f);
+            else
+                throughput = mul(throughput, divs(scl(cos_theta, bs.f), bs.pdf));
+            current_ray = make_ray(rec.p, bs.wi, current_ray.tm);
+        }
+        if (depth >= rr_start) {
+            double p_survive = std::max({throughput.x, throughput.y, throughput.z});
+            p_survive = clampd(p_survive, 0.05, 0.95);
+            if (g.next() > p_survive) break;
+            throughput = divs(throughput, p_survive);
+        }
+    }
+    return L;
+}
+
+/* ---- renderer/rr_path_integrator.h:21-59 -------------------------------------------------- */
+V3 li_rr(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g, Counters& cnt) {
+    V3 throughput = mk(1.0, 1.0, 1.0);
+    V3 L = mk(0.0, 0.0, 0.0);
+    Ray current_ray = r;
+    const V3 background = ld(sc.d->background);
+    for (int depth = 0; depth < max_depth; ++depth) {
+        Rec rec;
+        rec.u = rec.v = 0;
+        ++cnt.closest;
+        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) {
+            L = add(L, mul(throughput, background));
+            break;
+        }
+        V3 emitted = mat_emitted_legacy(sc, rec);
+        L = add(L, mul(throughput, emitted));
+        Ray scattered;
+        V3 attenuation;
+        if (!mat_scatter(sc, current_ray, rec, attenuation, scattered, g)) break;
+        throughput = mul(throughput, attenuation);
+        if (depth >= rr_start) {
+            double p_survive = std::max({throughput.x, throughput.y, throughput.z});
+            p_survive = clampd(p_survive, 0.005, 0.95);
+            if (g.next() > p_survive) break;
+            throughput = divs(throughput, p_survive);
+        }
+        current_ray = scattered;
+    }
+    return L;
+}
+
+/* one camera sample: renderer/renderer.h:73-78 under the seeded RNG */
+V3 camera_sample(const Scene& sc, const rtr_render_params& p, int i, int j, int s, uint32_t* rng_exit,
+                 Counters& cnt) {
+    Rng g{rtr_sample_seed_inline(p.seed, p.image_width, i, j, s)};
+    double u = (i + g.next()) / (p.image_width - 1);
+    double v = (j + g.next()) / (p.image_height - 1);
+    Ray r = camera_get_ray(sc.d->camera, u, v, g);
+    V3 L = p.integrator == RTR_INTEGRATOR_RR ? li_rr(sc, r, p.max_depth, p.rr_start_depth, g, cnt)
+                                             : li_mis(sc, r, p.max_depth, p.rr_start_depth, g, cnt);
+    if (rng_exit) *rng_exit = g.s;
+    return L;
+}
+
+bool params_ok(const rtr_scene_desc* sc, const rtr_render_params* p) {
+    if (!sc || !p || sc->root < 0 || sc->root >= sc->n_nodes) return false;
+    if (p->image_width < 2 || p->image_height < 2 || p->spp < 1) return false;
+    if (p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS) return false;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+/* Tile-threaded render of a region: the scheduling of renderer/renderer.h:40-94 (16x16
+ * tiles, one atomic tile counter, top row of tiles first, `threads` workers; 0 =
+ * hardware_concurrency) around the seeded per-sample loop.  Output layout and tile
+ * ownership as rtr_render_host() of rtr_hip.h.  stats = {samples, closest, shadow}. */
+int rto_render(const rtr_scene_desc* scene, const rtr_render_params* p, double* rgb, int64_t row_stride,
+               int threads, uint64_t* stats) {
+    if (!params_ok(scene, p) || !rgb) return RTR_ERR_INVALID;
+    Scene sc{scene};
+    const int W = p->image_width, H = p->image_height;
+    const int TILE = 16;
+    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+    const int total_tiles = tiles_x * tiles_y;
+    const int stride = p->tile_stride > 1 ? p->tile_stride : 1;
+    const int first = p->tile_stride > 1 ? p->tile_first : 0;
+    std::atomic<int> next_tile(0);
+    std::atomic<uint64_t> n_samples(0), n_closest(0), n_shadow(0);
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = 1;
+    auto worker = [&]() {
+        Counters cnt;
+        uint64_t samples = 0;
+        for (;;) {
+            int tile_index = next_tile.fetch_add(1);
+            if (tile_index >= total_tiles) break;
+            if (tile_index % stride != first) continue;
+            int tile_y = (tiles_y - 1) - tile_index / tiles_x;
+            int tile_x = tile_index % tiles_x;
+            int x_start = std::max(tile_x * TILE, p->x0), y_start = std::max(tile_y * TILE, p->y0);
+            int x_end = std::min(std::min(tile_x * TILE + TILE, W), p->x1);
+            int y_end = std::min(std::min(tile_y * TILE + TILE, H), p->y1);
+            for (int j = y_end - 1; j >= y_start; j--) {
+                for (int i = x_start; i < x_end; i++) {
+                    V3 pixel = mk(0, 0, 0);
+                    for (int s = 0; s < p->spp; ++s) pixel = add(pixel, camera_sample(sc, *p, i, j, s, nullptr, cnt));
+                    samples += (uint64_t)p->spp;
+                    double scale = 1.0 / p->spp; /* renderer.h:131 */
+                    double* o = rgb + ((int64_t)(j - p->y0) * row_stride + (i - p->x0)) * 3;
+                    o[0] = scale * pixel.x;
+                    o[1] = scale * pixel.y;
+                    o[2] = scale * pixel.z;
+                }
+            }
+        }
+        n_samples += samples;
+        n_closest += (uint64_t)cnt.closest;
+        n_shadow += (uint64_t)cnt.shadow;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+    if (stats) {
+        stats[0] = n_samples.load();
+        stats[1] = n_closest.load();
+        stats[2] = n_shadow.load();
+    }
+    return RTR_OK;
+}
+
+/* per-sample Li records: fills rng_exit, L, n_closest, n_shadow from (i, j, s) */
+int rto_li(const rtr_scene_desc* scene, const rtr_render_params* p, rtr_li_record* recs, int64_t n) {
+    if (!params_ok(scene, p) || !recs) return RTR_ERR_INVALID;
+    Scene sc{scene};
+    for (int64_t k = 0; k < n; ++k) {
+        Counters cnt;
+        V3 L = camera_sample(sc, *p, recs[k].i, recs[k].j, recs[k].s, &recs[k].rng_exit, cnt);
+        recs[k].L[0] = L.x, recs[k].L[1] = L.y, recs[k].L[2] = L.z;
+        recs[k].n_closest = (int32_t)cnt.closest;
+        recs[k].n_shadow = (int32_t)cnt.shadow;
+    }
+    return RTR_OK;
+}
+
+int rto_hits(const rtr_scene_desc* scene, rtr_hit_record* recs, int64_t n) {
+    if (!scene || !recs) return RTR_ERR_INVALID;
+    Scene sc{scene};
+    for (int64_t k = 0; k < n; ++k) {
+        rtr_hit_record& o = recs[k];
+        Ray r = make_ray(ld(o.o), ld(o.d), o.time);
+        Rng g{o.rng_in};
+        Rec rec;
+        rec.u = rec.v = std::numeric_limits<double>::quiet_NaN();
+        rec.mat = -1;
+        bool h = hit_node(sc, scene->root, r, o.t_min, o.t_max, rec, g);
+        o.rng_out = g.s;
+        o.hit = h;
+        o.front_face = 0, o.material = -1, o.pad = 0;
+        o.t = 0, o.u = 0, o.v = 0;
+        for (int c = 0; c < 3; ++c) o.p[c] = o.n[c] = 0;
+        if (h) {
+            o.front_face = rec.front_face;
+            o.material = rec.mat;
+            o.t = rec.t;
+            o.p[0] = rec.p.x, o.p[1] = rec.p.y, o.p[2] = rec.p.z;
+            o.n[0] = rec.normal.x, o.n[1] = rec.normal.y, o.n[2] = rec.normal.z;
+            o.u = rec.u, o.v = rec.v;
+        }
+    }
+    return RTR_OK;
+}
+
+int rto_materials(const rtr_scene_desc* scene, rtr_mat_record* recs, int64_t n) {
+    if (!scene || !recs) return RTR_ERR_INVALID;
+    Scene sc{scene};
+    for (int64_t k = 0; k < n; ++k) {
+        rtr_mat_record& o = recs[k];
+        if (o.material < 0 || o.material >= scene->n_materials) return RTR_ERR_INVALID;
+        Rec rec;
+        rec.p = ld(o.p), rec.normal = ld(o.n);
+        rec.u = o.u, rec.v = o.v, rec.t = 1.0;
+        rec.front_face = o.front_face != 0;
+        rec.mat = o.material;
+        V3 wo = ld(o.wo), wi = ld(o.wi_in);
+        Rng g{o.rng_in};
+        BSDFSample bs;
+        bs.wi = mk(0, 0, 0), bs.f = mk(0, 0, 0), bs.pdf = 0, bs.is_specular = false;
+        bool ok = mat_sample(sc, rec, wo, bs, g);
+        o.rng_out = g.s;
+        o.sample_ok = ok, o.is_specular = bs.is_specular, o.is_transmission = bs.is_transmission, o.pad = 0;
+        o.s_wi[0] = bs.wi.x, o.s_wi[1] = bs.wi.y, o.s_wi[2] = bs.wi.z;
+        o.s_f[0] = bs.f.x, o.s_f[1] = bs.f.y, o.s_f[2] = bs.f.z;
+        o.s_pdf = bs.pdf;
+        V3 e = mat_eval(sc, rec, wo, wi);
+        o.eval[0] = e.x, o.eval[1] = e.y, o.eval[2] = e.z;
+        o.pdf = mat_pdf(sc, rec, wo, wi);
+        V3 em = mat_emitted(sc, rec);
+        o.emitted[0] = em.x, o.emitted[1] = em.y, o.emitted[2] = em.z;
+    }
+    return RTR_OK;
+}
+
+int rto_lights(const rtr_scene_desc* scene, rtr_light_record* recs, int64_t n) {
+    if (!scene || !recs) return RTR_ERR_INVALID;
+    for (int64_t k = 0; k < n; ++k) {
+        rtr_light_record& o = recs[k];
+        if (o.light < 0 || o.light >= scene->n_lights) return RTR_ERR_INVALID;
+        const rtr_light& l = scene->lights[o.light];
+        LightSample s = light_sample(l, ld(o.p), o.u[0], o.u[1]);
+        o.Li[0] = s.Li.x, o.Li[1] = s.Li.y, o.Li[2] = s.Li.z;
+        o.wi[0] = s.wi.x, o.wi[1] = s.wi.y, o.wi[2] = s.wi.z;
+        o.pdf = s.pdf, o.dist = s.dist, o.is_delta = s.is_delta, o.pad2 = 0;
+        o.pdf_dir = light_pdf(l, ld(o.p), ld(o.dir));
+    }
+    return RTR_OK;
+}
+
+/* RNG known-answer block (layout: rtr_testrec.h RTR_RNG_BLOCK_DOUBLES) for one seed */
+int rto_rng_block(uint32_t seed, double* out) {
+    Rng g{seed};
+    int k = 0;
+    out[k++] = (double)seed;
+    for (int i = 0; i < 16; ++i) out[k++] = g.next();
+    for (int i = 0; i < 8; ++i) out[k++] = (double)g.irange(0, 9);
+    V3 a = rand_vec(g, -1, 1);
+    out[k++] = a.x, out[k++] = a.y, out[k++] = a.z;
+    double uy = g.next(), ux = g.next(); /* vec2 u(r(), r()), mis_path_integrator.h:205 */
+    out[k++] = ux, out[k++] = uy;
+    V3 d = random_in_unit_disk(g);
+    out[k++] = d.x, out[k++] = d.y, out[k++] = d.z;
+    V3 s = random_in_unit_sphere(g);
+    out[k++] = s.x, out[k++] = s.y, out[k++] = s.z;
+    V3 w = random_unit_vector(g);
+    out[k++] = w.x, out[k++] = w.y, out[k++] = w.z;
+    V3 c = random_cosine_direction(g);
+    out[k++] = c.x, out[k++] = c.y, out[k++] = c.z;
+    out[k++] = (double)g.s;
+    return k;
+}
+
+uint32_t rto_sample_seed(uint32_t seed, int32_t image_width, int32_t i, int32_t j, int32_t s) {
+    return rtr_sample_seed_inline(seed, image_width, i, j, s);
+}
+
+} /* extern "C" */

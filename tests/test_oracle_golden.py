@@ -1,0 +1,167 @@
+"""Pins the CPU oracle (oracle/rt_oracle.cpp) against the golden vectors that
+oracle/gen_golden.py produced by running the UNMODIFIED reference (oracle/_ref/ref_harness).
+
+The reference ships no tests, so these vectors are the only pins of the path.
+Everything here is bit-exact: the oracle restates the reference operation by operation in
+IEEE double, g++ without FMA contraction, and glibc libm on both sides.
+"""
+import numpy as np
+import pytest
+
+import _golden as G
+
+A = G.A
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def test_rng_known_answers():
+    """core/rtweekend.h:24-50 and the samplers of core/vec3.h:226-269, g++ argument order."""
+    gold = np.fromfile(G.os.path.join(G.GOLD, "rng.bin"), dtype="<f8").reshape(4, A.RNG_BLOCK_DOUBLES)
+    lib = G.oracle()
+    for row in gold:
+        out = np.zeros(A.RNG_BLOCK_DOUBLES)
+        n = lib.rto_rng_block(int(row[0]), out.ctypes.data)
+        assert n == A.RNG_BLOCK_DOUBLES
+        assert np.array_equal(_bits(out), _bits(row))
+
+
+def test_sample_seed_never_zero():
+    lib = G.oracle()
+    seen = set()
+    for i in range(0, 64, 7):
+        for j in range(0, 64, 5):
+            for s in range(3):
+                v = lib.rto_sample_seed(1, 64, i, j, s)
+                assert v != 0
+                seen.add(v)
+    assert len(seen) > 250  # distinct streams
+
+
+@pytest.mark.parametrize("sid", [21, 23, 9])
+def test_closest_hit_vectors(sid):
+    """hittable::hit on whole scenes: BVH order, wrappers, primitives, media RNG."""
+    sc = G.scene(sid)
+    gold = G.records("hits_scene%02d.bin" % sid, A.HIT_DTYPE)
+    out = G.oracle_records(sc, "rto_hits", gold)
+    assert np.array_equal(out["hit"], gold["hit"])
+    assert 0.2 < gold["hit"].mean() <= 1.0
+    assert np.array_equal(out["rng_out"], gold["rng_out"])
+    h = gold["hit"] == 1
+    for f in ("front_face", "material"):
+        assert np.array_equal(out[f][h], gold[f][h]), f
+    for f in ("t", "p", "n"):
+        assert np.array_equal(_bits(out[f][h]), _bits(gold[f][h])), f
+    # u,v: only where the reference sets them (moving_sphere / constant_medium leave them unset)
+    uv = h & ~np.isnan(gold["u"])
+    assert uv.sum() > 0
+    for f in ("u", "v"):
+        assert np.array_equal(_bits(out[f][uv]), _bits(gold[f][uv])), f
+        assert np.all(np.isnan(out[f][h & ~uv]))
+    if sid == 9:  # media consumed RNG inside traversal
+        assert np.any(gold["rng_in"] != gold["rng_out"])
+
+
+@pytest.mark.parametrize("sid", [23, 9])
+def test_material_vectors(sid):
+    """material::sample / eval / pdf / emitted (materials/material.h), textures, perlin."""
+    sc = G.scene(sid)
+    gold = G.records("materials_scene%02d.bin" % sid, A.MAT_DTYPE)
+    out = G.oracle_records(sc, "rto_materials", gold)
+    for f in ("sample_ok", "rng_out", "is_transmission"):
+        assert np.array_equal(out[f], gold[f]), f
+    for f in ("eval", "pdf", "emitted"):
+        assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
+    # the reference leaves `sampled` untouched for materials without sample(); where it writes, compare
+    types = sc.materials["type"][gold["material"]]
+    writes = np.isin(types, [A.MAT_LAMBERTIAN, A.MAT_METAL, A.MAT_DIELECTRIC])
+    ok = writes | ((types == A.MAT_PBR) & (gold["sample_ok"] == 1))
+    for f in ("s_wi", "s_f", "s_pdf"):
+        assert np.array_equal(_bits(out[f][ok]), _bits(gold[f][ok])), f
+    assert np.array_equal(out["is_specular"][ok], gold["is_specular"][ok])
+    assert set(np.unique(types)) >= ({A.MAT_LAMBERTIAN, A.MAT_DIELECTRIC, A.MAT_DIFFUSE_LIGHT})
+
+
+@pytest.mark.parametrize("sid", [21, 23])
+def test_light_vectors(sid):
+    """QuadLight::sample / pdf (lighting/quad_light.h:18-77)."""
+    sc = G.scene(sid)
+    gold = G.records("lights_scene%02d.bin" % sid, A.LIGHTREC_DTYPE)
+    out = G.oracle_records(sc, "rto_lights", gold)
+    for f in ("Li", "wi", "pdf", "dist", "pdf_dir"):
+        assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
+    assert (gold["pdf"] > 0).any() and (gold["pdf"] == 0).any()
+
+
+LI_CASES = [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4)]
+
+
+@pytest.mark.parametrize("sid,integ", LI_CASES)
+def test_li_records(sid, integ):
+    """Integrator::Li per camera sample: radiance, RNG state at exit (draw count), segment counts."""
+    name = "li_scene%02d_i%d.bin" % (sid, integ)
+    info = G.MANIFEST["files"][name]
+    sc = G.scene(sid)
+    gold = G.records(name, A.LI_DTYPE)
+    p = A.make_params(info["info"]["width"], info["info"]["height"], info["spp"], integrator=integ,
+                      seed=info["seed"])
+    out = G.oracle_records(sc, "rto_li", gold, params=p)
+    assert np.array_equal(out["rng_exit"], gold["rng_exit"])
+    assert np.array_equal(out["n_closest"], gold["n_closest"])
+    assert np.array_equal(out["n_shadow"], gold["n_shadow"])
+    assert np.array_equal(_bits(out["L"]), _bits(gold["L"]))
+    assert gold["n_closest"].max() > 4
+
+
+IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_scene21_i4_64_spp16.f64",
+             "img_scene23_i4_64_spp16.f64", "img_scene09_i1_64_spp16.f64", "img_scene22_i4_64_spp16.f64",
+             "img_scene21_i4_128_spp32.f64"]
+
+
+@pytest.mark.parametrize("name", IMG_CASES)
+def test_images(name):
+    """Whole tile-threaded render (renderer/renderer.h:40-94) == reference, bit for bit."""
+    img, info = G.image(name)
+    sc = G.scene(info["scene"])
+    p = A.make_params(info["width"], info["height"], info["spp"], integrator=info["integrator"], seed=info["seed"])
+    out, stats = G.oracle_render(sc, p, threads=4)
+    assert stats["samples"] == info["width"] * info["height"] * info["spp"]
+    assert stats["closest_segments"] == info["info"]["closest_segments"]
+    assert stats["shadow_segments"] == info["info"]["shadow_segments"]
+    assert np.array_equal(_bits(out), _bits(img))
+    assert G.rel_l2(out, img) == 0.0
+
+
+def test_scene07_integrator4_is_nearly_black():
+    """the literal BASELINE config (scene07 + MIS) only sees the light's back face."""
+    dark, _ = G.image("img_scene07_i4_64_spp16.f64")
+    lit, _ = G.image("img_scene21_i4_64_spp16.f64")
+    assert dark.mean() < 0.05 * lit.mean()
+
+
+def test_tile_sharding_partitions_the_image():
+    """tile_first/tile_stride own disjoint 16x16 tiles whose union is the whole image."""
+    sc = G.scene(21)
+    full, _ = G.oracle_render(sc, A.make_params(40, 40, 2), threads=2)
+    acc = np.zeros_like(full)
+    cover = np.zeros(full.shape[:2], dtype=int)
+    for r in range(3):
+        p = A.make_params(40, 40, 2, tile_first=r, tile_stride=3)
+        part = np.full((40, 40, 3), np.nan)
+        lib = G.oracle()
+        d = sc.desc()
+        assert lib.rto_render(G.C.byref(d), G.C.byref(p), part.ctypes.data, 40, 1, None) == 0
+        own = ~np.isnan(part[..., 0])
+        cover += own
+        acc[own] = part[own]
+    assert np.all(cover == 1)
+    assert np.array_equal(acc, full)
+
+
+def test_region_matches_full_image():
+    sc = G.scene(23)
+    full, _ = G.oracle_render(sc, A.make_params(48, 27, 3), threads=2)
+    sub, _ = G.oracle_render(sc, A.make_params(48, 27, 3, region=(5, 3, 37, 20)), threads=2)
+    assert np.array_equal(sub, full[3:20, 5:37])
