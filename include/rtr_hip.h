@@ -203,7 +203,11 @@ typedef struct rtr_render_params {
      * renders every tile. */
     int32_t tile_first;
     int32_t tile_stride;
-    int32_t reserved[2];
+    /* The spp samples of a pixel may be summed as `spp_chunks` consecutive partial sums that
+     * are then added in order (more parallelism on small images).  1 = one running sum in
+     * sample order, exactly like renderer.h:72-79; 0 = let the library choose. */
+    int32_t spp_chunks;
+    int32_t reserved;
 } rtr_render_params;
 
 typedef struct rtr_render_stats {

@@ -1,0 +1,38 @@
+/*
+ * rtr_hip_test.h -- auxiliary entry points of librtr_hip.so used by the parity tests:
+ * a host-only scene check, and device unit kernels that run the library's own device
+ * functions over golden-vector records (include/rtr_testrec.h), one lane per record.
+ * They exist so tests can compare the HIP path with the oracle below the whole-image
+ * level; a renderer integration only needs rtr_hip.h.
+ */
+#ifndef RTR_HIP_TEST_H
+#define RTR_HIP_TEST_H
+
+#include "rtr_hip.h"
+#include "rtr_testrec.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtr_scene_info {
+    int32_t stack_words; /* LDS traversal-stack words per lane the scene needs */
+    int32_t has_media;   /* constant_medium present: RNG is consumed inside traversal */
+    int32_t needs_uv;    /* some texture reads (u,v) */
+    int32_t graph_depth; /* longest root-to-leaf chain of hittables */
+} rtr_scene_info;
+
+/* Host-only: the checks rtr_upload_scene() runs before touching the GPU.  Returns RTR_OK,
+ * RTR_ERR_INVALID or RTR_ERR_UNSUPPORTED; `msg` (may be NULL) receives the reason. */
+int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* msg, size_t msg_cap);
+
+/* In-place on HOST arrays of records: inputs are read, outputs overwritten. */
+int rtr_test_hits(rtr_context* ctx, rtr_hit_record* recs, int64_t n);
+int rtr_test_materials(rtr_context* ctx, rtr_mat_record* recs, int64_t n);
+int rtr_test_lights(rtr_context* ctx, rtr_light_record* recs, int64_t n);
+int rtr_test_li(rtr_context* ctx, const rtr_render_params* params, rtr_li_record* recs, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTR_HIP_TEST_H */

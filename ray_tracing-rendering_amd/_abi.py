@@ -81,7 +81,7 @@ class RenderParamsC(C.Structure):
                 ("x1", C.c_int32), ("y1", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("rr_start_depth", C.c_int32), ("integrator", C.c_int32), ("seed", C.c_uint32),
                 ("pipeline", C.c_int32), ("tile_first", C.c_int32), ("tile_stride", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("spp_chunks", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RenderStatsC(C.Structure):
@@ -90,7 +90,7 @@ class RenderStatsC(C.Structure):
 
 
 def make_params(width, height, spp, *, integrator=INTEGRATOR_MIS, seed=1, max_depth=50, rr_start_depth=3,
-                region=None, pipeline=PIPELINE_AUTO, tile_first=0, tile_stride=1):
+                region=None, pipeline=PIPELINE_AUTO, tile_first=0, tile_stride=1, spp_chunks=1):
     """Build an ``rtr_render_params``.  Defaults follow the reference driver (main.cpp:102,
     mis_path_integrator.h:237)."""
     x0, y0, x1, y1 = region if region is not None else (0, 0, width, height)
@@ -100,4 +100,5 @@ def make_params(width, height, spp, *, integrator=INTEGRATOR_MIS, seed=1, max_de
     p.spp, p.max_depth, p.rr_start_depth = int(spp), int(max_depth), int(rr_start_depth)
     p.integrator, p.seed, p.pipeline = int(integrator), int(seed) & 0xFFFFFFFF, int(pipeline)
     p.tile_first, p.tile_stride = int(tile_first), int(tile_stride)
+    p.spp_chunks = int(spp_chunks)
     return p

@@ -1,0 +1,940 @@
+/*
+ * rt_device.h -- gfx950 device functions of the path tracer: vector math, xorshift32,
+ * hittable-graph traversal with an LDS stack, textures, materials, lights, camera and the
+ * two integrator bounce loops.  Shared by the megakernel and the wavefront stage kernels
+ * (rt_kernels.hip).
+ *
+ * Numerics contract ("exact" build, -ffp-contract=off): every expression keeps the
+ * reference's operation order in IEEE binary64 (division and sqrt correctly rounded), so
+ * results are bit-identical to the reference wherever no libm transcendental is involved
+ * (all of the Cornell scenes); sin/cos/pow/log/acos/atan2 come from OCML and may differ
+ * from glibc in the last ulp (scenes 23, 9, 22).  RNG draws are sequenced in the order
+ * g++ evaluates the reference's argument lists.
+ *
+ * Citations are reference paths relative to /root/reference/src.
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtr_hip.h"
+#include "rtr_seed.h"
+
+#ifndef RTR_BLOCK
+#define RTR_BLOCK 256 /* threads per workgroup = one 16x16 tile (renderer/renderer.h:40) */
+#endif
+
+#define RT_DEV __device__ __forceinline__
+
+typedef double Real;
+
+#define RT_INF (__builtin_huge_val())
+#define RT_PI 3.1415926535897932385 /* core/rtweekend.h:18 */
+
+/* ---- core/vec3.h:12-224 --------------------------------------------------------------- */
+struct V3 {
+    Real x, y, z;
+};
+RT_DEV V3 mk(Real x, Real y, Real z) {
+    V3 r;
+    r.x = x, r.y = y, r.z = z;
+    return r;
+}
+RT_DEV V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+RT_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_DEV V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV V3 scl(Real t, V3 v) { return mk(t * v.x, t * v.y, t * v.z); }
+RT_DEV V3 divs(V3 v, Real t) { return scl(1 / t, v); } /* vec3.h:208-210: multiply by 1/t */
+RT_DEV Real dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV V3 cross(V3 u, V3 v) { return mk(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x); }
+RT_DEV Real len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RT_DEV Real len(V3 a) { return __builtin_sqrt(len2(a)); }
+RT_DEV V3 unit(V3 v) { return divs(v, len(v)); }
+RT_DEV bool near_zero(V3 a) { /* vec3.h:81-85 */
+    const Real s = 1e-8;
+    return (__builtin_fabs(a.x) < s) && (__builtin_fabs(a.y) < s) && (__builtin_fabs(a.z) < s);
+}
+RT_DEV V3 reflect(V3 v, V3 n) { return sub(v, scl(2 * dot(v, n), n)); } /* vec3.h:239-241 */
+RT_DEV V3 refract(V3 uv, V3 n, Real etai_over_etat) {                    /* vec3.h:243-248 */
+    Real cos_theta = __builtin_fmin(dot(neg(uv), n), 1.0);
+    V3 r_out_perp = scl(etai_over_etat, add(uv, scl(cos_theta, n)));
+    V3 r_out_parallel = scl(-__builtin_sqrt(__builtin_fabs(1.0 - len2(r_out_perp))), n);
+    return add(r_out_perp, r_out_parallel);
+}
+RT_DEV Real clampd(Real x, Real lo, Real hi) { /* rtweekend.h:40-46 */
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+RT_DEV Real max3(V3 a) { /* std::max({x,y,z}) */
+    Real m = a.x;
+    if (m < a.y) m = a.y;
+    if (m < a.z) m = a.z;
+    return m;
+}
+RT_DEV Real maxd(Real a, Real b) { return a < b ? b : a; } /* std::max(a,b) */
+
+/* ---- core/rtweekend.h:24-50 ------------------------------------------------------------ */
+RT_DEV Real rng_next(uint32_t& s) {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return s * 2.3283064365386963e-10;
+}
+RT_DEV Real rng_range(uint32_t& s, Real lo, Real hi) { return lo + (hi - lo) * rng_next(s); }
+RT_DEV int rng_int(uint32_t& s, int lo, int hi) { return (int)rng_range(s, lo, hi + 1); }
+
+/* vec3::random(-1,1) accepted into the unit ball (vec3.h:226-233); z takes the first draw */
+RT_DEV V3 random_in_unit_sphere(uint32_t& s) {
+    for (;;) {
+        Real z = rng_range(s, -1, 1);
+        Real y = rng_range(s, -1, 1);
+        Real x = rng_range(s, -1, 1);
+        V3 p = mk(x, y, z);
+        if (len2(p) >= 1) continue;
+        return p;
+    }
+}
+RT_DEV V3 random_unit_vector(uint32_t& s) { return unit(random_in_unit_sphere(s)); }
+RT_DEV V3 random_in_unit_disk(uint32_t& s) { /* vec3.h:250-257; y first */
+    for (;;) {
+        Real y = rng_range(s, -1, 1);
+        Real x = rng_range(s, -1, 1);
+        V3 p = mk(x, y, 0);
+        if (len2(p) >= 1) continue;
+        return p;
+    }
+}
+RT_DEV V3 random_cosine_direction(uint32_t& s) { /* vec3.h:261-269 */
+    Real r1 = rng_next(s);
+    Real r2 = rng_next(s);
+    Real z = __builtin_sqrt(1 - r2);
+    Real phi = 2 * RT_PI * r1;
+    Real x = cos(phi) * __builtin_sqrt(r2);
+    Real y = sin(phi) * __builtin_sqrt(r2);
+    return mk(x, y, z);
+}
+
+/* ---- device scene ------------------------------------------------------------------------ */
+struct DScene {
+    const rtr_node* nodes;
+    const int32_t* list_children;
+    const rtr_material* materials;
+    const rtr_texture* textures;
+    const rtr_perlin* perlin;
+    const rtr_image* images;
+    const uint8_t* image_bytes;
+    const rtr_light* lights;
+    rtr_camera camera;
+    double background[3];
+    int32_t root;
+    int32_t n_nodes;
+    int32_t n_lights;
+    int32_t needs_uv; /* some texture reads (u,v): image textures */
+};
+
+struct Hit { /* geometry/hittable.h:10-23 */
+    V3 p, n;
+    Real t, u, v;
+    int mat;
+    bool front;
+};
+
+RT_DEV void set_face_normal(Hit& rec, V3 rd, V3 outward) { /* hittable.h:19-22 */
+    rec.front = dot(rd, outward) < 0;
+    rec.n = rec.front ? outward : neg(outward);
+}
+
+/* ---- per-lane traversal stack in LDS, interleaved so lane l owns bank l%32 ------------------ */
+struct Stack {
+    int* col; /* &lds[threadIdx.x]; entry k lives at col[k*RTR_BLOCK] */
+    RT_DEV void put(int k, int v) const { col[k * RTR_BLOCK] = v; }
+    RT_DEV int get(int k) const { return col[k * RTR_BLOCK]; }
+    RT_DEV void putd(int k, Real v) const {
+        put(k, __double2loint(v));
+        put(k + 1, __double2hiint(v));
+    }
+    RT_DEV Real getd(int k) const { return __hiloint2double(get(k + 1), get(k)); }
+};
+
+/* stack words used by the wrapper frames (must match the analysis in rtr_capi.hip) */
+#define RT_FRAME_TRANSLATE 8 /* o.xyz (6) + hits + marker */
+#define RT_FRAME_ROTATE 14   /* o.x o.z d.x d.z inv.x inv.z (12) + hits + marker */
+#define RT_FRAME_FLIP 2      /* hits + marker */
+
+/* geometry/aabb.h:31-48 with ray.h's cached inv_dir / dir_sign */
+RT_DEV bool aabb_hit(const double* b, V3 o, V3 inv, Real t_min, Real t_max) {
+    {
+        Real t0 = (b[0] - o.x) * inv.x, t1 = (b[3] - o.x) * inv.x;
+        if (inv.x < 0) {
+            Real s = t0;
+            t0 = t1, t1 = s;
+        }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        Real t0 = (b[1] - o.y) * inv.y, t1 = (b[4] - o.y) * inv.y;
+        if (inv.y < 0) {
+            Real s = t0;
+            t0 = t1, t1 = s;
+        }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        Real t0 = (b[2] - o.z) * inv.z, t1 = (b[5] - o.z) * inv.z;
+        if (inv.z < 0) {
+            Real s = t0;
+            t0 = t1, t1 = s;
+        }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+RT_DEV void sphere_uv(V3 p, Real& u, Real& v) { /* geometry/sphere.h:24-30 */
+    Real theta = acos(-p.y);
+    Real phi = atan2(-p.z, p.x) + RT_PI;
+    u = phi / (2 * RT_PI);
+    v = theta / RT_PI;
+}
+
+/*
+ * Closest hit of the hittable graph under `root`: an iterative restatement of the
+ * reference's recursive virtual hit() calls that visits objects in the same order
+ * (bvh_node: left then right, right limited by the left's t, geometry/bvh.h:40-50;
+ * hittable_list in order, hittable_list.h:33-47), so ties resolve the same way and the
+ * RNG draws of constant_medium::hit happen in the same sequence.
+ *
+ * FULL = false computes only whether/where (t) something is hit (shadow rays, medium
+ * boundaries); MEDIA enables constant_medium nodes (never nested: checked at upload).  Returns whether anything was hit; `tmax` returns the hit t.
+ */
+template <bool FULL, bool MEDIA>
+__device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d, Real time, Real tmin, Real& tmax,
+                                         Hit& rec, uint32_t& rng, const Stack st, const int sp0) {
+    V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* core/ray.h:11-12 */
+    int hits = 0;
+    int sp = sp0;
+    st.put(sp++, root);
+    while (sp > sp0) {
+        const int e = st.get(--sp);
+        if (e < 0) { /* leaving wrapper node -(e+1) */
+            const rtr_node& n = sc.nodes[-(e + 1)];
+            const bool inside = st.get(--sp) != hits;
+            const int type = n.type;
+            if (type == RTR_NODE_TRANSLATE) { /* geometry/hittable.h:58-61 */
+                if (FULL && inside) {
+                    rec.p = add(rec.p, ld3(n.f));
+                    set_face_normal(rec, d, rec.n);
+                }
+                sp -= 6;
+                o = mk(st.getd(sp), st.getd(sp + 2), st.getd(sp + 4));
+            } else if (type == RTR_NODE_ROTATE_Y) { /* geometry/hittable.h:142-155 */
+                if (FULL && inside) {
+                    const Real s = n.f[0], c = n.f[1];
+                    V3 p = rec.p, nn = rec.n;
+                    p.x = c * rec.p.x + s * rec.p.z;
+                    p.z = -s * rec.p.x + c * rec.p.z;
+                    nn.x = c * rec.n.x + s * rec.n.z;
+                    nn.z = -s * rec.n.x + c * rec.n.z;
+                    rec.p = p;
+                    set_face_normal(rec, d, nn);
+                }
+                sp -= 12;
+                o.x = st.getd(sp), o.z = st.getd(sp + 2);
+                d.x = st.getd(sp + 4), d.z = st.getd(sp + 6);
+                inv.x = st.getd(sp + 8), inv.z = st.getd(sp + 10);
+            } else { /* flip_face, geometry/hittable.h:163-170 */
+                if (FULL && inside) rec.front = !rec.front;
+            }
+            continue;
+        }
+        const rtr_node& n = sc.nodes[e];
+        const int type = n.type;
+        if (type == RTR_NODE_BVH) {
+            if (aabb_hit(n.f, o, inv, tmin, tmax)) {
+                st.put(sp++, n.b);
+                st.put(sp++, n.a);
+            }
+        } else if (type >= RTR_NODE_XY_RECT) { /* geometry/aarect.h:79-135 */
+            const Real k = n.f[4];
+            Real ok, dk, oa, da, ob, db;
+            if (type == RTR_NODE_XY_RECT) {
+                ok = o.z, dk = d.z, oa = o.x, da = d.x, ob = o.y, db = d.y;
+            } else if (type == RTR_NODE_XZ_RECT) {
+                ok = o.y, dk = d.y, oa = o.x, da = d.x, ob = o.z, db = d.z;
+            } else {
+                ok = o.x, dk = d.x, oa = o.y, da = d.y, ob = o.z, db = d.z;
+            }
+            const Real t = (k - ok) / dk;
+            if (!(t < tmin || t > tmax)) {
+                const Real a = oa + t * da;
+                const Real b = ob + t * db;
+                if (!(a < n.f[0] || a > n.f[1] || b < n.f[2] || b > n.f[3])) {
+                    tmax = t;
+                    ++hits;
+                    if (FULL) {
+                        if (sc.needs_uv) {
+                            rec.u = (a - n.f[0]) / (n.f[1] - n.f[0]);
+                            rec.v = (b - n.f[2]) / (n.f[3] - n.f[2]);
+                        }
+                        rec.t = t;
+                        V3 outward = mk(type == RTR_NODE_YZ_RECT ? 1.0 : 0.0, type == RTR_NODE_XZ_RECT ? 1.0 : 0.0,
+                                        type == RTR_NODE_XY_RECT ? 1.0 : 0.0);
+                        set_face_normal(rec, d, outward);
+                        rec.mat = n.a;
+                        rec.p = add(o, scl(t, d));
+                    }
+                }
+            }
+        } else if (type == RTR_NODE_SPHERE || type == RTR_NODE_MOVING_SPHERE) {
+            /* geometry/sphere.h:33-60, geometry/moving_sphere.h:32-62 */
+            V3 center;
+            Real radius;
+            if (type == RTR_NODE_SPHERE) {
+                center = ld3(n.f);
+                radius = n.f[3];
+            } else {
+                V3 c0 = ld3(n.f), c1 = ld3(n.f + 3);
+                center = add(c0, scl((time - n.f[6]) / (n.f[7] - n.f[6]), sub(c1, c0)));
+                radius = n.f[8];
+            }
+            V3 oc = sub(o, center);
+            Real a = len2(d);
+            Real half_b = dot(oc, d);
+            Real c = len2(oc) - radius * radius;
+            Real discriminant = half_b * half_b - a * c;
+            if (!(discriminant < 0)) {
+                Real sqrtd = __builtin_sqrt(discriminant);
+                Real root_t = (-half_b - sqrtd) / a;
+                bool ok = true;
+                if (root_t < tmin || root_t > tmax) {
+                    root_t = (-half_b + sqrtd) / a;
+                    if (root_t < tmin || root_t > tmax) ok = false;
+                }
+                if (ok) {
+                    tmax = root_t;
+                    ++hits;
+                    if (FULL) {
+                        rec.t = root_t;
+                        rec.p = add(o, scl(root_t, d));
+                        V3 outward = divs(sub(rec.p, center), radius);
+                        set_face_normal(rec, d, outward);
+                        if (type == RTR_NODE_SPHERE && sc.needs_uv) sphere_uv(outward, rec.u, rec.v);
+                        rec.mat = n.a;
+                    }
+                }
+            }
+        } else if (type == RTR_NODE_LIST) {
+            for (int k = n.b - 1; k >= 0; --k) st.put(sp++, sc.list_children[n.a + k]);
+        } else if (type == RTR_NODE_TRANSLATE) { /* geometry/hittable.h:51-56 */
+            st.putd(sp, o.x), st.putd(sp + 2, o.y), st.putd(sp + 4, o.z);
+            sp += 6;
+            st.put(sp++, hits);
+            st.put(sp++, -(e + 1));
+            o = sub(o, ld3(n.f));
+            st.put(sp++, n.a);
+        } else if (type == RTR_NODE_ROTATE_Y) { /* geometry/hittable.h:127-140 */
+            st.putd(sp, o.x), st.putd(sp + 2, o.z), st.putd(sp + 4, d.x), st.putd(sp + 6, d.z);
+            st.putd(sp + 8, inv.x), st.putd(sp + 10, inv.z);
+            sp += 12;
+            st.put(sp++, hits);
+            st.put(sp++, -(e + 1));
+            const Real s = n.f[0], c = n.f[1];
+            const Real ox = c * o.x - s * o.z, oz = s * o.x + c * o.z;
+            const Real dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
+            o.x = ox, o.z = oz, d.x = dx, d.z = dz;
+            inv.x = 1.0 / d.x, inv.z = 1.0 / d.z;
+            st.put(sp++, n.a);
+        } else if (type == RTR_NODE_FLIP_FACE) {
+            st.put(sp++, hits);
+            st.put(sp++, -(e + 1));
+            st.put(sp++, n.a);
+        } else if (MEDIA && type == RTR_NODE_MEDIUM) { /* geometry/constant_medium.h:55-104 */
+            Hit dummy;
+            Real t1 = RT_INF;
+            if (traverse<false, false>(sc, n.a, o, d, time, -RT_INF, t1, dummy, rng, st, sp)) {
+                Real t2 = RT_INF;
+                if (traverse<false, false>(sc, n.a, o, d, time, t1 + 0.0001, t2, dummy, rng, st, sp)) {
+                    if (t1 < tmin) t1 = tmin;
+                    if (t2 > tmax) t2 = tmax;
+                    if (!(t1 >= t2)) {
+                        if (t1 < 0) t1 = 0;
+                        const Real ray_length = len(d);
+                        const Real distance_inside_boundary = (t2 - t1) * ray_length;
+                        const Real hit_distance = n.f[0] * log(rng_next(rng));
+                        if (!(hit_distance > distance_inside_boundary)) {
+                            tmax = t1 + hit_distance / ray_length;
+                            ++hits;
+                            if (FULL) {
+                                rec.t = tmax;
+                                rec.p = add(o, scl(tmax, d));
+                                rec.n = mk(1, 0, 0);
+                                rec.front = true;
+                                rec.mat = n.b;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return hits > 0;
+}
+
+/* ---- materials/perlin.h:21-111 -------------------------------------------------------------- */
+RT_DEV Real perlin_noise(const rtr_perlin& pn, V3 p) {
+    const Real fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    const Real u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const Real uu = u * u * (3 - 2 * u);
+    const Real vv = v * v * (3 - 2 * v);
+    const Real ww = w * w * (3 - 2 * w);
+    Real accum = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int ix = pn.perm_x[(i + a) & 255] ^ pn.perm_y[(j + b) & 255] ^ pn.perm_z[(k + c) & 255];
+                V3 cv = ld3(pn.ranvec[ix]);
+                V3 weight_v = mk(u - a, v - b, w - c);
+                accum += (a * uu + (1 - a) * (1 - uu)) * (b * vv + (1 - b) * (1 - vv)) *
+                         (c * ww + (1 - c) * (1 - ww)) * dot(cv, weight_v);
+            }
+    return accum;
+}
+RT_DEV Real perlin_turb(const rtr_perlin& pn, V3 p) { /* perlin.h:41-54 */
+    Real accum = 0.0;
+    V3 temp_p = p;
+    Real weight = 1.0;
+    for (int i = 0; i < 7; i++) {
+        accum += weight * perlin_noise(pn, temp_p);
+        weight *= 0.5;
+        temp_p = mk(temp_p.x * 2, temp_p.y * 2, temp_p.z * 2);
+    }
+    return __builtin_fabs(accum);
+}
+
+/* ---- materials/texture.h:11-162 ----------------------------------------------------------------- */
+__device__ inline V3 tex_value(const DScene& sc, int ix, Real u, Real v, V3 p) {
+    /* checker textures nest (texture.h:60-66); unrolled to a bounded loop instead of recursion */
+    for (int guard = 0; guard < 8; ++guard) {
+        const rtr_texture& t = sc.textures[ix];
+        const int type = t.type;
+        if (type == RTR_TEX_SOLID) return ld3(t.f);
+        if (type == RTR_TEX_CHECKER) { /* texture.h:68-75 */
+            Real sines = sin(10 * p.x) * sin(10 * p.y) * sin(10 * p.z);
+            ix = sines < 0 ? t.b : t.a;
+            continue;
+        }
+        if (type == RTR_TEX_NOISE) { /* texture.h:155-158 */
+            Real x = 1 + sin(t.f[0] * p.z + 10 * perlin_turb(sc.perlin[t.a], p));
+            return scl(x, mk(0.5, 0.5, 0.5));
+        }
+        /* image_texture, texture.h:115-139 */
+        if (t.a < 0) return mk(0, 1, 1);
+        const rtr_image& im = sc.images[t.a];
+        u = clampd(u, 0.0, 1.0);
+        v = 1.0 - clampd(v, 0.0, 1.0);
+        int i = (int)(u * im.width);
+        int j = (int)(v * im.height);
+        if (i >= im.width) i = im.width - 1;
+        if (j >= im.height) j = im.height - 1;
+        const Real color_scale = 1.0 / 255.0;
+        const uint8_t* px = sc.image_bytes + im.offset + (size_t)j * 3 * im.width + (size_t)i * 3;
+        return mk(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
+    }
+    return mk(0, 0, 0);
+}
+RT_DEV Real tex_scalar(const DScene& sc, int ix, Real u, Real v, V3 p) { return tex_value(sc, ix, u, v, p).x; }
+RT_DEV V3 tex_normal(const DScene& sc, int ix, Real u, Real v, V3 p) { /* texture.h:19-22 */
+    V3 c = tex_value(sc, ix, u, v, p);
+    return unit(sub(scl(2.0, c), mk(1, 1, 1)));
+}
+
+/* ---- core/onb.h:24-37 ------------------------------------------------------------------------------- */
+struct Onb {
+    V3 u, v, w;
+};
+RT_DEV Onb onb_from_w(V3 n) {
+    Onb b;
+    b.w = unit(n);
+    V3 a = (__builtin_fabs(b.w.x) > 0.9) ? mk(0, 1, 0) : mk(1, 0, 0);
+    b.v = unit(cross(b.w, a));
+    b.u = cross(b.w, b.v);
+    return b;
+}
+RT_DEV V3 onb_local(const Onb& b, V3 a) { return add(add(scl(a.x, b.u), scl(a.y, b.v)), scl(a.z, b.w)); }
+
+/* ---- materials/material.h ------------------------------------------------------------------------------ */
+struct BSDFSample { /* material.h:13-20 */
+    V3 wi, f;
+    Real pdf;
+    bool is_specular;
+    bool is_transmission; /* write-only in the reference; kept for the unit vectors */
+};
+
+RT_DEV Real distribution_ggx(V3 N, V3 H, Real roughness) { /* material.h:398-409 */
+    Real a = roughness * roughness;
+    Real a2 = a * a;
+    Real NdotH = maxd(dot(N, H), 0.0);
+    Real NdotH2 = NdotH * NdotH;
+    Real denom = (NdotH2 * (a2 - 1.0) + 1.0);
+    denom = RT_PI * denom * denom;
+    return a2 / denom;
+}
+RT_DEV Real geometry_schlick_ggx(Real NdotV, Real roughness) { /* material.h:411-419 */
+    Real k = (roughness * roughness) / 2.0;
+    Real denom = NdotV * (1.0 - k) + k;
+    return NdotV / denom;
+}
+RT_DEV Real geometry_smith(V3 N, V3 V, V3 L, Real roughness) { /* material.h:421-428 */
+    Real NdotV = maxd(dot(N, V), 0.0);
+    Real NdotL = maxd(dot(N, L), 0.0);
+    Real ggx2 = geometry_schlick_ggx(NdotV, roughness);
+    Real ggx1 = geometry_schlick_ggx(NdotL, roughness);
+    return ggx1 * ggx2;
+}
+RT_DEV V3 fresnel_schlick(Real cosTheta, V3 F0) { /* material.h:430-432 */
+    return add(F0, scl(pow(1.0 - cosTheta, 5.0), sub(mk(1, 1, 1), F0)));
+}
+RT_DEV V3 pbr_normal(const DScene& sc, const rtr_material& m, const Hit& rec) { /* material.h:247-261 */
+    V3 N = rec.n;
+    if (m.tex[3] >= 0) {
+        V3 ax0;
+        if (__builtin_fabs(N.y) > 0.999)
+            ax0 = mk(1, 0, 0);
+        else
+            ax0 = unit(cross(N, mk(0, 1, 0)));
+        V3 ax1 = cross(N, ax0);
+        V3 ln = tex_normal(sc, m.tex[3], rec.u, rec.v, rec.p);
+        N = unit(add(add(scl(ln.x, ax0), scl(ln.y, ax1)), scl(ln.z, N)));
+    }
+    return N;
+}
+__device__ inline Real pbr_pdf(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
+    /* material.h:305-340 */
+    V3 N = pbr_normal(sc, m, rec);
+    if (dot(N, wi) <= 0) return 0;
+    Real rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
+    rough = clampd(rough, 0.01, 1.0);
+    Real pdf_diff = dot(N, wi) / RT_PI;
+    V3 H = unit(add(wo, wi));
+    Real D = distribution_ggx(N, H, rough);
+    Real NdotH = maxd(dot(N, H), 0.0);
+    Real HdotV = maxd(dot(H, wo), 0.0);
+    Real pdf_spec = (D * NdotH) / (4.0 * HdotV + 0.0001);
+    return 0.5 * pdf_diff + 0.5 * pdf_spec;
+}
+__device__ inline V3 pbr_eval(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
+    /* material.h:342-396 */
+    V3 N = pbr_normal(sc, m, rec);
+    Real NdotL = dot(N, wi);
+    Real NdotV = dot(N, wo);
+    if (NdotL <= 0 || NdotV <= 0) return mk(0, 0, 0);
+    Real rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
+    Real metal = tex_scalar(sc, m.tex[2], rec.u, rec.v, rec.p);
+    V3 base_color = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    rough = clampd(rough, 0.01, 1.0);
+    V3 H = unit(add(wo, wi));
+    V3 F0 = mk(0.04, 0.04, 0.04);
+    V3 metal_vec = mk(metal, metal, metal);
+    F0 = add(mul(sub(mk(1.0, 1.0, 1.0), metal_vec), F0), mul(metal_vec, base_color));
+    V3 F = fresnel_schlick(maxd(dot(H, wo), 0.0), F0);
+    Real D = distribution_ggx(N, H, rough);
+    Real G = geometry_smith(N, wo, wi, rough);
+    V3 numerator = scl(D * G, F);
+    Real denominator = 4.0 * NdotV * NdotL + 0.0001;
+    V3 specular = divs(numerator, denominator);
+    V3 kD = sub(mk(1.0, 1.0, 1.0), F);
+    kD = scl(1.0 - metal, kD);
+    V3 diffuse = divs(mul(kD, base_color), RT_PI);
+    return add(diffuse, specular);
+}
+RT_DEV Real reflectance(Real cosine, Real ref_idx) { /* material.h:199-203 */
+    Real r0 = (1 - ref_idx) / (1 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1 - r0) * pow((1 - cosine), 5.0);
+}
+
+/* material::emitted(rec, wo): material.h:32-34, :222-227 (front face only) */
+RT_DEV V3 mat_emitted(const DScene& sc, const Hit& rec) {
+    const rtr_material& m = sc.materials[rec.mat];
+    if (m.type == RTR_MAT_DIFFUSE_LIGHT && rec.front) return tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    return mk(0, 0, 0);
+}
+/* material::emitted(u, v, p): material.h:27-29, :218-220 (two-sided) */
+RT_DEV V3 mat_emitted_legacy(const DScene& sc, const Hit& rec) {
+    const rtr_material& m = sc.materials[rec.mat];
+    if (m.type == RTR_MAT_DIFFUSE_LIGHT) return tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    return mk(0, 0, 0);
+}
+
+__device__ inline bool mat_sample(const DScene& sc, const Hit& rec, V3 wo, BSDFSample& s, uint32_t& rng) {
+    const rtr_material& m = sc.materials[rec.mat];
+    const int type = m.type;
+    if (type == RTR_MAT_LAMBERTIAN) { /* material.h:79-90 */
+        V3 scatter_direction = add(rec.n, random_unit_vector(rng));
+        if (near_zero(scatter_direction)) scatter_direction = rec.n;
+        s.wi = unit(scatter_direction);
+        s.pdf = dot(rec.n, s.wi) / RT_PI;
+        s.f = divs(tex_value(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
+        s.is_specular = false;
+        return true;
+    }
+    if (type == RTR_MAT_METAL) { /* material.h:123-131 */
+        V3 reflected = reflect(unit(neg(wo)), rec.n);
+        s.wi = unit(add(reflected, scl(m.f[3], random_in_unit_sphere(rng))));
+        s.f = ld3(m.f);
+        s.pdf = 1.0;
+        s.is_specular = true;
+        return dot(s.wi, rec.n) > 0;
+    }
+    if (type == RTR_MAT_DIELECTRIC) { /* material.h:152-174 */
+        s.f = mk(1.0, 1.0, 1.0);
+        s.is_specular = true;
+        s.pdf = 1.0;
+        Real ir = m.f[0];
+        Real refraction_ratio = rec.front ? (1.0 / ir) : ir;
+        V3 unit_direction = neg(wo);
+        Real cos_theta = __builtin_fmin(dot(neg(unit_direction), rec.n), 1.0);
+        Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_next(rng)) {
+            s.wi = reflect(unit_direction, rec.n);
+            s.is_transmission = false;
+        } else {
+            s.wi = refract(unit_direction, rec.n, refraction_ratio);
+            s.is_transmission = true;
+        }
+        return true;
+    }
+    if (type == RTR_MAT_PBR) { /* material.h:245-303 */
+        V3 N = pbr_normal(sc, m, rec);
+        Real rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
+        rough = clampd(rough, 0.01, 1.0);
+        if (rng_next(rng) < 0.5) {
+            Onb uvw = onb_from_w(N);
+            Real r1 = rng_next(rng);
+            Real r2 = rng_next(rng);
+            Real a = rough * rough;
+            Real phi = 2.0 * RT_PI * r1;
+            Real cos_theta = __builtin_sqrt((1.0 - r2) / (1.0 + (a * a - 1.0) * r2));
+            Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+            V3 H_local = mk(sin_theta * cos(phi), sin_theta * sin(phi), cos_theta);
+            V3 H = onb_local(uvw, H_local);
+            V3 L = reflect(neg(wo), H);
+            if (dot(N, L) <= 0) return false;
+            s.wi = L;
+        } else {
+            Onb uvw = onb_from_w(N);
+            V3 L = onb_local(uvw, random_cosine_direction(rng));
+            if (dot(N, L) <= 0) L = N;
+            s.wi = unit(L);
+        }
+        s.is_specular = false;
+        s.pdf = pbr_pdf(sc, m, rec, wo, s.wi);
+        s.f = pbr_eval(sc, m, rec, wo, s.wi);
+        if (s.pdf < 1e-6) return false;
+        return true;
+    }
+    return false; /* diffuse_light (material.h:213-216), isotropic (base class, :42-45) */
+}
+
+/* material::eval: base 0 (material.h:48-51), lambertian without hemisphere test (:98-101), PBR (:342) */
+RT_DEV V3 mat_eval(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
+    const rtr_material& m = sc.materials[rec.mat];
+    if (m.type == RTR_MAT_LAMBERTIAN) return divs(tex_value(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
+    if (m.type == RTR_MAT_PBR) return pbr_eval(sc, m, rec, wo, wi);
+    return mk(0, 0, 0);
+}
+/* material::pdf: base 0 (material.h:54-57), lambertian (:92-96), PBR (:305) */
+RT_DEV Real mat_pdf(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
+    const rtr_material& m = sc.materials[rec.mat];
+    if (m.type == RTR_MAT_LAMBERTIAN) {
+        Real cosine = dot(rec.n, unit(wi));
+        return cosine < 0 ? 0 : cosine / RT_PI;
+    }
+    if (m.type == RTR_MAT_PBR) return pbr_pdf(sc, m, rec, wo, wi);
+    return 0.0;
+}
+/* legacy material::scatter(r_in, rec, attenuation, scattered): new ray = (rec.p, dir, r_in.time) */
+__device__ inline bool mat_scatter(const DScene& sc, V3 rd, const Hit& rec, V3& attenuation, V3& out_dir,
+                                   uint32_t& rng) {
+    const rtr_material& m = sc.materials[rec.mat];
+    const int type = m.type;
+    if (type == RTR_MAT_LAMBERTIAN) { /* material.h:103-112 */
+        V3 scatter_direction = add(rec.n, random_unit_vector(rng));
+        if (near_zero(scatter_direction)) scatter_direction = rec.n;
+        out_dir = scatter_direction;
+        attenuation = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+        return true;
+    }
+    if (type == RTR_MAT_METAL) { /* material.h:133-140 */
+        V3 reflected = reflect(unit(rd), rec.n);
+        out_dir = add(reflected, scl(m.f[3], random_in_unit_sphere(rng)));
+        attenuation = ld3(m.f);
+        return dot(out_dir, rec.n) > 0;
+    }
+    if (type == RTR_MAT_DIELECTRIC) { /* material.h:176-193 */
+        attenuation = mk(1.0, 1.0, 1.0);
+        Real ir = m.f[0];
+        Real refraction_ratio = rec.front ? (1.0 / ir) : ir;
+        V3 unit_direction = unit(rd);
+        Real cos_theta = __builtin_fmin(dot(neg(unit_direction), rec.n), 1.0);
+        Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_next(rng))
+            out_dir = reflect(unit_direction, rec.n);
+        else
+            out_dir = refract(unit_direction, rec.n, refraction_ratio);
+        return true;
+    }
+    if (type == RTR_MAT_ISOTROPIC) { /* geometry/constant_medium.h:19-24 */
+        out_dir = random_in_unit_sphere(rng);
+        attenuation = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+        return true;
+    }
+    return false; /* diffuse_light (material.h:229-232), PBRMaterial (base class, :66-69) */
+}
+
+/* ---- lighting/quad_light.h:18-77 --------------------------------------------------------------------------- */
+struct LightSample {
+    V3 Li, wi;
+    Real pdf, dist;
+};
+RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy) {
+    LightSample s;
+    V3 light_point = add(add(ld3(l.f), scl(ux, ld3(l.f + 3))), scl(uy, ld3(l.f + 6)));
+    V3 d = sub(light_point, p);
+    Real dist_sq = len2(d);
+    s.dist = __builtin_sqrt(dist_sq);
+    s.wi = divs(d, s.dist);
+    Real cos_theta = dot(neg(s.wi), ld3(l.f + 12));
+    if (cos_theta <= 0) {
+        s.Li = mk(0, 0, 0);
+        s.pdf = 0;
+        return s;
+    }
+    s.Li = ld3(l.f + 9);
+    s.pdf = dist_sq / (l.f[15] * cos_theta);
+    return s;
+}
+RT_DEV Real light_pdf(const rtr_light& l, V3 origin, V3 direction) {
+    V3 Q = ld3(l.f), U = ld3(l.f + 3), Vv = ld3(l.f + 6), normal = ld3(l.f + 12);
+    Real denom = dot(direction, normal);
+    if (denom >= -1e-6) return 0;
+    Real t = dot(sub(Q, origin), normal) / denom;
+    if (t < 0.001 || t > RT_INF) return 0;
+    V3 planar = sub(add(origin, scl(t, direction)), Q);
+    Real alpha = dot(planar, U) / len2(U);
+    Real beta = dot(planar, Vv) / len2(Vv);
+    if (alpha < 0 || alpha > 1 || beta < 0 || beta > 1) return 0;
+    Real dist_sq = t * t * len2(direction);
+    Real cos_theta = -denom / len(direction);
+    return dist_sq / (l.f[15] * cos_theta);
+}
+
+/* ---- renderer/camera.h:32-40 --------------------------------------------------------------------------------- */
+RT_DEV void camera_get_ray(const rtr_camera& c, Real s, Real t, uint32_t& rng, V3& o, V3& d, Real& tm) {
+    V3 rd = scl(c.lens_radius, random_in_unit_disk(rng));
+    V3 offset = add(scl(rd.x, ld3(c.u)), scl(rd.y, ld3(c.v)));
+    V3 origin = ld3(c.origin);
+    d = sub(sub(add(add(ld3(c.lower_left_corner), scl(s, ld3(c.horizontal))), scl(t, ld3(c.vertical))), origin),
+            offset);
+    o = add(origin, offset);
+    tm = rng_range(rng, c.time0, c.time1);
+}
+
+/* ---- renderer/mis_path_integrator.h helpers -------------------------------------------------------------------- */
+RT_DEV V3 clamp_radiance(V3 L) { /* :154-162, max_value = 100 */
+    const Real max_value = 100.0;
+    if (L.x > max_value || L.y > max_value || L.z > max_value) {
+        Real max_c = max3(L);
+        if (max_c > max_value) return scl(max_value / max_c, L);
+    }
+    return L;
+}
+RT_DEV Real power_heuristic(Real pdf_a, Real pdf_b) { /* :165-170 */
+    Real a2 = pdf_a * pdf_a;
+    Real b2 = pdf_b * pdf_b;
+    Real denom = a2 + b2;
+    return denom > 0 ? a2 / denom : 0.0;
+}
+RT_DEV Real compute_light_pdf(const DScene& sc, V3 o, V3 d) { /* :173-188 */
+    Real total_pdf = 0.0;
+    Real light_select_pdf = 1.0 / sc.n_lights;
+    for (int k = 0; k < sc.n_lights; ++k) total_pdf += light_pdf(sc.lights[k], o, d) * light_select_pdf;
+    return total_pdf;
+}
+
+struct PathCounters {
+    uint32_t closest, shadow;
+};
+
+/* The per-path state both integrators carry from bounce to bounce
+ * (mis_path_integrator.h:28-32, rr_path_integrator.h:23-25). */
+struct PathState {
+    V3 ro, rd; /* current_ray origin / direction (direction is not normalised) */
+    Real tm;   /* current_ray.time() */
+    V3 thr;    /* throughput */
+    V3 L;      /* radiance gathered by this camera sample */
+    Real prev_bsdf_pdf;
+    int depth;
+    bool specular_bounce;
+};
+RT_DEV void path_begin(PathState& ps, V3 ro, V3 rd, Real tm) {
+    ps.ro = ro, ps.rd = rd, ps.tm = tm;
+    ps.thr = mk(1.0, 1.0, 1.0);
+    ps.L = mk(0.0, 0.0, 0.0);
+    ps.prev_bsdf_pdf = 0.0;
+    ps.depth = 0;
+    ps.specular_bounce = false;
+}
+
+/* a next-event-estimation connection waiting for its shadow ray */
+struct ShadowReq {
+    bool valid;
+    V3 wi;      /* shadow_ray = ray(rec.p, wi, time 0), mis_path_integrator.h:210 */
+    Real tmax;  /* ls.dist - 0.001 */
+    V3 contrib; /* clamp_radiance(throughput * L_direct) if unshadowed */
+};
+
+/*
+ * MISPathIntegrator::Li, first half of one loop iteration after a hit
+ * (mis_path_integrator.h:69-103): emitted radiance with its MIS weight, then the light
+ * sample of sample_lights_mis (:191-229).  The BSDF value and pdf are evaluated before the
+ * shadow test (the reference evaluates them after it; they draw no random numbers), so the
+ * connection can be resolved later by a separate shadow-ray stage.
+ */
+RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, ShadowReq& rq) {
+    const bool have_lights = sc.n_lights > 0;
+    V3 emitted = mat_emitted(sc, rec);
+    if (len2(emitted) > 0) { /* :72-94 */
+        V3 L_emit;
+        if (ps.depth == 0 || ps.specular_bounce) {
+            L_emit = mul(ps.thr, emitted);
+        } else if (have_lights) {
+            Real mis_weight = power_heuristic(ps.prev_bsdf_pdf, compute_light_pdf(sc, ps.ro, ps.rd));
+            L_emit = scl(mis_weight, mul(ps.thr, emitted));
+        } else {
+            L_emit = mul(ps.thr, emitted);
+        }
+        ps.L = add(ps.L, ps.depth == 0 ? L_emit : clamp_radiance(L_emit));
+    }
+    rq.valid = false;
+    /* material::is_specular() is never overridden, so NEE runs at every hit */
+    if (have_lights) {
+        const int light_idx = rng_int(rng, 0, sc.n_lights - 1);
+        const rtr_light& light = sc.lights[light_idx];
+        const Real light_select_pdf = 1.0 / sc.n_lights;
+        const Real uy = rng_next(rng); /* vec2 u(r(), r()): u.y takes the first draw (g++ order) */
+        const Real ux = rng_next(rng);
+        LightSample ls = light_sample(light, rec.p, ux, uy);
+        if (ls.pdf > 0 && len2(ls.Li) > 0) {
+            V3 f = mat_eval(sc, rec, wo, ls.wi);
+            Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));
+            Real bsdf_pdf = mat_pdf(sc, rec, wo, ls.wi);
+            Real lpdf = ls.pdf * light_select_pdf;
+            Real mis_weight = power_heuristic(lpdf, bsdf_pdf);
+            V3 L_direct = divs(scl(mis_weight, scl(cos_theta, mul(f, ls.Li))), lpdf);
+            rq.valid = true;
+            rq.wi = ls.wi;
+            rq.tmax = ls.dist - 0.001;
+            rq.contrib = clamp_radiance(mul(ps.thr, L_direct));
+        }
+    }
+}
+
+/* second half (mis_path_integrator.h:105-146): BSDF sampling with the legacy scatter()
+ * fallback, throughput update, Russian roulette.  Returns false when the path ends. */
+RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, int rr_start) {
+    BSDFSample bs;
+    if (!mat_sample(sc, rec, wo, bs, rng)) { /* :106-118 */
+        V3 attenuation, ndir;
+        if (!mat_scatter(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+        ps.thr = mul(ps.thr, attenuation);
+        ps.ro = rec.p, ps.rd = ndir;
+        ps.specular_bounce = false;
+        ps.prev_bsdf_pdf = 0.0;
+    } else {
+        if (bs.pdf < 1e-8 && !bs.is_specular) return false;
+        ps.specular_bounce = bs.is_specular;
+        ps.prev_bsdf_pdf = bs.is_specular ? 0.0 : bs.pdf;
+        Real cos_theta = __builtin_fabs(dot(bs.wi, rec.n));
+        if (bs.is_specular)
+            ps.thr = mul(ps.thr, bs.f);
+        else
+            ps.thr = mul(ps.thr, divs(scl(cos_theta, bs.f), bs.pdf));
+        ps.ro = rec.p, ps.rd = bs.wi;
+    }
+    if (ps.depth >= rr_start) { /* :137-146 */
+        Real p_survive = clampd(max3(ps.thr), 0.05, 0.95);
+        if (rng_next(rng) > p_survive) return false;
+        ps.thr = divs(ps.thr, p_survive);
+    }
+    return true;
+}
+
+/* RRPathInterator::Li after a hit (rr_path_integrator.h:36-55): two-sided legacy emission,
+ * legacy scatter(), roulette clamp [0.005, 0.95] tested before the ray moves on. */
+RT_DEV bool shade_rr(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& rng, int rr_start) {
+    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy(sc, rec)));
+    V3 attenuation, ndir;
+    if (!mat_scatter(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+    ps.thr = mul(ps.thr, attenuation);
+    if (ps.depth >= rr_start) {
+        Real p_survive = clampd(max3(ps.thr), 0.005, 0.95);
+        if (rng_next(rng) > p_survive) return false;
+        ps.thr = divs(ps.thr, p_survive);
+    }
+    ps.ro = rec.p, ps.rd = ndir;
+    return true;
+}
+
+/*
+ * One whole loop iteration of Integrator::Li in registers (megakernel / unit tests):
+ * closest hit, shading, inline shadow ray.  Returns false when the camera sample is
+ * finished (ps.L is then its radiance).
+ */
+template <int INTEG, bool MEDIA>
+__device__ __forceinline__ bool bounce(const DScene& sc, PathState& ps, uint32_t& rng, const Stack st,
+                                       int max_depth, int rr_start, PathCounters& cnt) {
+    Hit rec;
+    rec.u = 0, rec.v = 0;
+    Real tmax = RT_INF;
+    ++cnt.closest;
+    if (!traverse<true, MEDIA>(sc, sc.root, ps.ro, ps.rd, ps.tm, 0.001, tmax, rec, rng, st, 0)) {
+        /* mis_path_integrator.h:48-49 / rr_path_integrator.h:31-33; no infinite light is flattened */
+        ps.L = add(ps.L, mul(ps.thr, ld3(sc.background)));
+        return false;
+    }
+    bool go;
+    if (INTEG == RTR_INTEGRATOR_MIS) {
+        V3 wo = neg(unit(ps.rd));
+        ShadowReq rq;
+        shade_a_mis(sc, ps, rec, wo, rng, rq);
+        if (rq.valid) {
+            Hit srec;
+            Real smax = rq.tmax;
+            ++cnt.shadow;
+            if (!traverse<false, MEDIA>(sc, sc.root, rec.p, rq.wi, 0.0, 0.001, smax, srec, rng, st, 0))
+                ps.L = add(ps.L, rq.contrib);
+        } /* else the reference adds clamp_radiance(throughput * 0) = +0 (:99-103): no effect */
+        go = shade_b_mis(sc, ps, rec, wo, rng, rr_start);
+    } else {
+        go = shade_rr(sc, ps, rec, rng, rr_start);
+    }
+    if (!go) return false;
+    return ++ps.depth < max_depth;
+}

@@ -1,0 +1,220 @@
+/*
+ * rt_kernels.h -- __global__ kernels of the path tracer (gfx950).
+ *
+ *  k_mega      megakernel: one workgroup = one 16x16 image tile (renderer/renderer.h:40-67),
+ *              one lane = one pixel.  A lane runs its samples back to back: when a path ends
+ *              the lane starts its pixel's next camera sample in the same loop iteration
+ *              (in-lane path regeneration), so the 64 lanes of a wave stay busy although path
+ *              lengths differ (P(k=4)=0.45, long tail).  Samples of a pixel are
+ *              summed in sample order like renderer.h:72-79.
+ *  k_resolve   adds the per-chunk partial sums of a pixel in chunk order, scales by 1/spp
+ *              (renderer.h:131) and stores linear mean radiance.
+ *  k_test_*    one lane per golden-vector record (include/rtr_testrec.h): device unit parity.
+ */
+#pragma once
+
+#include "rt_device.h"
+#include "rtr_testrec.h"
+
+struct RenderK {
+    int W, H;
+    int x0, y0, x1, y1;
+    int spp, max_depth, rr_start;
+    uint32_t seed;
+    int tiles_x, tiles_y;
+    const int* tile_ids; /* owned tiles, reference dispatch numbering (renderer.h:61-62) */
+    int n_tiles;
+    int chunks;
+    double* partial;             /* [n_tiles*chunks][3][RTR_BLOCK] un-normalised sums */
+    unsigned long long* stats;   /* samples, closest segments, shadow segments */
+    const int* cancel;           /* set by rtr_cancel() */
+};
+
+RT_DEV void tile_pixel(const RenderK& P, int slot, int tid, int& i, int& j, bool& active) {
+    const int tile = P.tile_ids[slot];
+    const int tile_y = (P.tiles_y - 1) - tile / P.tiles_x; /* renderer.h:61-62 */
+    const int tile_x = tile % P.tiles_x;
+    i = tile_x * 16 + (tid & 15);
+    j = tile_y * 16 + (tid >> 4);
+    active = i >= P.x0 && i < P.x1 && j >= P.y0 && j < P.y1;
+}
+
+RT_DEV unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <int INTEG, bool MEDIA>
+__global__ void __launch_bounds__(RTR_BLOCK) k_mega(const DScene sc, const RenderK P) {
+    extern __shared__ int lds_stack[];
+    const Stack st{lds_stack + threadIdx.x};
+    const int slot = blockIdx.x / P.chunks, chunk = blockIdx.x % P.chunks;
+    int i, j;
+    bool active;
+    tile_pixel(P, slot, threadIdx.x, i, j, active);
+    /* samples [s, s_end) of this pixel belong to this chunk */
+    int s = (int)((long long)chunk * P.spp / P.chunks);
+    const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+    V3 acc = mk(0, 0, 0);
+    PathCounters cnt;
+    cnt.closest = 0, cnt.shadow = 0;
+    uint32_t n_samples = 0;
+    PathState ps;
+    uint32_t rng = 1;
+    bool fresh = true;
+    bool done = !active || s >= s_end;
+    while (!done) {
+        if (fresh) { /* renderer.h:73-75 under the per-sample seed */
+            if (__hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
+            const Real u = (i + rng_next(rng)) / (P.W - 1);
+            const Real v = (j + rng_next(rng)) / (P.H - 1);
+            V3 ro, rd;
+            Real tm;
+            camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
+            path_begin(ps, ro, rd, tm);
+            fresh = false;
+        }
+        if (!bounce<INTEG, MEDIA>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
+            acc = add(acc, ps.L); /* renderer.h:77-78 */
+            ++n_samples;
+            ++s;
+            fresh = true;
+            done = s >= s_end;
+        }
+    }
+    double* out = P.partial + (size_t)blockIdx.x * 3 * RTR_BLOCK + threadIdx.x;
+    out[0] = acc.x;
+    out[RTR_BLOCK] = acc.y;
+    out[2 * RTR_BLOCK] = acc.z;
+    unsigned long long a = wave_sum(n_samples), b = wave_sum(cnt.closest), c = wave_sum(cnt.shadow);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&P.stats[0], a);
+        atomicAdd(&P.stats[1], b);
+        atomicAdd(&P.stats[2], c);
+    }
+}
+
+struct ResolveK {
+    RenderK r;
+    double* out; /* linear mean radiance, 3 doubles per pixel */
+    long long row_stride;
+};
+
+__global__ void __launch_bounds__(RTR_BLOCK) k_resolve(const ResolveK R) {
+    const RenderK& P = R.r;
+    int i, j;
+    bool active;
+    tile_pixel(P, blockIdx.x, threadIdx.x, i, j, active);
+    if (!active) return;
+    const double* in = P.partial + (size_t)blockIdx.x * P.chunks * 3 * RTR_BLOCK + threadIdx.x;
+    double r = 0, g = 0, b = 0;
+    for (int c = 0; c < P.chunks; ++c) {
+        if (c == 0) {
+            r = in[0], g = in[RTR_BLOCK], b = in[2 * RTR_BLOCK];
+        } else {
+            r += in[0], g += in[RTR_BLOCK], b += in[2 * RTR_BLOCK];
+        }
+        in += 3 * RTR_BLOCK;
+    }
+    const double scale = 1.0 / P.spp; /* renderer.h:131 */
+    double* o = R.out + ((long long)(j - P.y0) * R.row_stride + (i - P.x0)) * 3;
+    o[0] = scale * r;
+    o[1] = scale * g;
+    o[2] = scale * b;
+}
+
+/* ---- device unit kernels over golden-vector records ---------------------------------------- */
+template <bool MEDIA>
+__global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hit_record* recs, long long n) {
+    extern __shared__ int lds_stack[];
+    const Stack st{lds_stack + threadIdx.x};
+    const long long k = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    rtr_hit_record r = recs[k];
+    uint32_t rng = r.rng_in;
+    Hit rec;
+    rec.u = rec.v = __builtin_nan("");
+    rec.mat = -1;
+    rec.t = 0, rec.p = mk(0, 0, 0), rec.n = mk(0, 0, 0), rec.front = false;
+    Real tmax = r.t_max;
+    const bool h = traverse<true, MEDIA>(sc, sc.root, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, rec, rng, st, 0);
+    r.rng_out = rng;
+    r.hit = h;
+    r.front_face = h ? (int)rec.front : 0;
+    r.material = h ? rec.mat : -1;
+    r.pad = 0;
+    r.t = h ? rec.t : 0;
+    r.p[0] = h ? rec.p.x : 0, r.p[1] = h ? rec.p.y : 0, r.p[2] = h ? rec.p.z : 0;
+    r.n[0] = h ? rec.n.x : 0, r.n[1] = h ? rec.n.y : 0, r.n[2] = h ? rec.n.z : 0;
+    r.u = h ? rec.u : 0, r.v = h ? rec.v : 0;
+    recs[k] = r;
+}
+
+__global__ void __launch_bounds__(RTR_BLOCK) k_test_materials(const DScene sc, rtr_mat_record* recs, long long n) {
+    const long long k = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    rtr_mat_record r = recs[k];
+    Hit rec;
+    rec.p = ld3(r.p), rec.n = ld3(r.n);
+    rec.u = r.u, rec.v = r.v, rec.t = 1.0;
+    rec.front = r.front_face != 0;
+    rec.mat = r.material;
+    const V3 wo = ld3(r.wo), wi = ld3(r.wi_in);
+    uint32_t rng = r.rng_in;
+    BSDFSample bs;
+    bs.wi = mk(0, 0, 0), bs.f = mk(0, 0, 0), bs.pdf = 0, bs.is_specular = false, bs.is_transmission = false;
+    const bool ok = mat_sample(sc, rec, wo, bs, rng);
+    r.rng_out = rng;
+    r.sample_ok = ok, r.is_specular = bs.is_specular, r.pad = 0;
+    r.is_transmission = bs.is_transmission;
+    r.s_wi[0] = bs.wi.x, r.s_wi[1] = bs.wi.y, r.s_wi[2] = bs.wi.z;
+    r.s_f[0] = bs.f.x, r.s_f[1] = bs.f.y, r.s_f[2] = bs.f.z;
+    r.s_pdf = bs.pdf;
+    const V3 e = mat_eval(sc, rec, wo, wi);
+    r.eval[0] = e.x, r.eval[1] = e.y, r.eval[2] = e.z;
+    r.pdf = mat_pdf(sc, rec, wo, wi);
+    const V3 em = mat_emitted(sc, rec);
+    r.emitted[0] = em.x, r.emitted[1] = em.y, r.emitted[2] = em.z;
+    recs[k] = r;
+}
+
+__global__ void __launch_bounds__(RTR_BLOCK) k_test_lights(const DScene sc, rtr_light_record* recs, long long n) {
+    const long long k = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    rtr_light_record r = recs[k];
+    const rtr_light& l = sc.lights[r.light];
+    LightSample s = light_sample(l, ld3(r.p), r.u[0], r.u[1]);
+    r.Li[0] = s.Li.x, r.Li[1] = s.Li.y, r.Li[2] = s.Li.z;
+    r.wi[0] = s.wi.x, r.wi[1] = s.wi.y, r.wi[2] = s.wi.z;
+    r.pdf = s.pdf, r.dist = s.dist, r.is_delta = 0, r.pad2 = 0;
+    r.pdf_dir = light_pdf(l, ld3(r.p), ld3(r.dir));
+    recs[k] = r;
+}
+
+template <int INTEG, bool MEDIA>
+__global__ void __launch_bounds__(RTR_BLOCK) k_test_li(const DScene sc, const RenderK P, rtr_li_record* recs,
+                                                        long long n) {
+    extern __shared__ int lds_stack[];
+    const Stack st{lds_stack + threadIdx.x};
+    const long long k = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    rtr_li_record r = recs[k];
+    uint32_t rng = rtr_sample_seed_inline(P.seed, P.W, r.i, r.j, r.s);
+    const Real u = (r.i + rng_next(rng)) / (P.W - 1);
+    const Real v = (r.j + rng_next(rng)) / (P.H - 1);
+    V3 ro, rd;
+    Real tm;
+    camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
+    PathState ps;
+    path_begin(ps, ro, rd, tm);
+    PathCounters cnt;
+    cnt.closest = 0, cnt.shadow = 0;
+    while (bounce<INTEG, MEDIA>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
+    }
+    r.rng_exit = rng;
+    r.L[0] = ps.L.x, r.L[1] = ps.L.y, r.L[2] = ps.L.z;
+    r.n_closest = (int)cnt.closest, r.n_shadow = (int)cnt.shadow;
+    recs[k] = r;
+}

@@ -1,0 +1,682 @@
+/*
+ * rtr_capi.hip -- implementation of the C ABI (include/rtr_hip.h) on top of the HIP
+ * kernels of rt_kernels.h.  Host side only: scene validation and upload, launch geometry,
+ * workspace, cancel, statistics.  Built by hipcc for gfx950 into librtr_hip.so.
+ */
+#include "rt_kernels.h"
+#include "rt_wavefront.h"
+#include "rtr_hip_test.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct rtr_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr; /* cancel flag writes */
+    std::string err;
+    /* scene */
+    bool has_scene = false;
+    rtr_scene_info info{};
+    DScene ds{};
+    DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
+    /* per-render workspace */
+    DevBuf b_tiles, b_partial, b_stats, b_cancel, b_test;
+    WavefrontPool pool;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool stats_pending = false;
+    rtr_render_stats stats{};
+    std::atomic<int> cancel_requested{0};
+    std::mutex cancel_mu;
+};
+
+namespace {
+
+int fail(rtr_context* c, int code, const std::string& msg) {
+    if (c)
+        c->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, RTR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+int ensure(rtr_context* c, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return RTR_OK;
+    if (b.p) {
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(c, RTR_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    b.cap = bytes;
+    return RTR_OK;
+}
+
+int upload(rtr_context* c, DevBuf& b, const void* src, size_t bytes) {
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return RTR_OK;
+}
+
+/* ---- host-only scene validation + traversal stack analysis -------------------------------- */
+struct Validator {
+    const rtr_scene_desc* s;
+    std::string msg;
+    std::vector<int> state;  /* 0 new, 1 on DFS stack, 2 done */
+    std::vector<int> need;   /* stack words used below a node (see traverse()) */
+    std::vector<int> depth;
+    std::vector<char> media; /* subtree contains a constant_medium */
+    int code = RTR_OK;
+
+    bool bad(int c, const std::string& m) {
+        if (code == RTR_OK) {
+            code = c;
+            msg = m;
+        }
+        return false;
+    }
+    bool node_ix(int i) const { return i >= 0 && i < s->n_nodes; }
+
+    bool texture_ok(int ix, int guard) {
+        if (ix < 0 || ix >= s->n_textures) return bad(RTR_ERR_INVALID, "texture index out of range");
+        if (guard > 7) return bad(RTR_ERR_UNSUPPORTED, "checker textures nested deeper than 8");
+        const rtr_texture& t = s->textures[ix];
+        switch (t.type) {
+        case RTR_TEX_SOLID: return true;
+        case RTR_TEX_CHECKER: return texture_ok(t.a, guard + 1) && texture_ok(t.b, guard + 1);
+        case RTR_TEX_NOISE:
+            if (t.a < 0 || t.a >= s->n_perlin) return bad(RTR_ERR_INVALID, "perlin table index out of range");
+            return true;
+        case RTR_TEX_IMAGE:
+            if (t.a >= s->n_images) return bad(RTR_ERR_INVALID, "image index out of range");
+            if (t.a >= 0) {
+                const rtr_image& im = s->images[t.a];
+                if (im.width <= 0 || im.height <= 0 ||
+                    im.offset + (uint64_t)im.width * im.height * 3 > s->n_image_bytes)
+                    return bad(RTR_ERR_INVALID, "image texels out of range");
+            }
+            return true;
+        default: return bad(RTR_ERR_UNSUPPORTED, "unknown texture type");
+        }
+    }
+
+    bool material_ok(int ix) {
+        if (ix < 0 || ix >= s->n_materials) return bad(RTR_ERR_INVALID, "material index out of range");
+        const rtr_material& m = s->materials[ix];
+        switch (m.type) {
+        case RTR_MAT_LAMBERTIAN:
+        case RTR_MAT_DIFFUSE_LIGHT:
+        case RTR_MAT_ISOTROPIC: return texture_ok(m.tex[0], 0);
+        case RTR_MAT_METAL:
+        case RTR_MAT_DIELECTRIC: return true;
+        case RTR_MAT_PBR:
+            if (!texture_ok(m.tex[0], 0) || !texture_ok(m.tex[1], 0) || !texture_ok(m.tex[2], 0)) return false;
+            return m.tex[3] < 0 || texture_ok(m.tex[3], 0);
+        default: return bad(RTR_ERR_UNSUPPORTED, "unknown material type");
+        }
+    }
+
+    /* iterative post-order DFS over the hittable DAG */
+    bool walk(int root) {
+        struct Frame {
+            int node, next;
+        };
+        std::vector<Frame> stk;
+        stk.push_back({root, 0});
+        state[root] = 1;
+        std::vector<int> kids;
+        while (!stk.empty()) {
+            Frame& f = stk.back();
+            const rtr_node& n = s->nodes[f.node];
+            kids.clear();
+            switch (n.type) {
+            case RTR_NODE_BVH: kids = {n.a, n.b}; break;
+            case RTR_NODE_LIST:
+                if (n.a < 0 || n.b < 0 || (int64_t)n.a + n.b > s->n_list_children)
+                    return bad(RTR_ERR_INVALID, "hittable_list children out of range");
+                kids.assign(s->list_children + n.a, s->list_children + n.a + n.b);
+                break;
+            case RTR_NODE_TRANSLATE:
+            case RTR_NODE_ROTATE_Y:
+            case RTR_NODE_FLIP_FACE: kids = {n.a}; break;
+            case RTR_NODE_MEDIUM:
+                if (!material_ok(n.b)) return false;
+                kids = {n.a};
+                break;
+            case RTR_NODE_SPHERE:
+            case RTR_NODE_MOVING_SPHERE:
+            case RTR_NODE_XY_RECT:
+            case RTR_NODE_XZ_RECT:
+            case RTR_NODE_YZ_RECT:
+                if (!material_ok(n.a)) return false;
+                break;
+            default: return bad(RTR_ERR_UNSUPPORTED, "unknown hittable node type");
+            }
+            if (f.next < (int)kids.size()) {
+                int k = kids[f.next++];
+                if (!node_ix(k)) return bad(RTR_ERR_INVALID, "hittable child index out of range");
+                if (state[k] == 1) return bad(RTR_ERR_INVALID, "hittable graph has a cycle");
+                if (state[k] == 0) {
+                    state[k] = 1;
+                    stk.push_back({k, 0});
+                }
+                continue;
+            }
+            /* children done: stack words, depth, media */
+            const int me = f.node;
+            int u = 0, d = 0;
+            char md = 0;
+            const int m = (int)kids.size();
+            for (int k : kids) {
+                d = std::max(d, depth[k]);
+                md |= media[k];
+            }
+            switch (n.type) {
+            case RTR_NODE_BVH: u = std::max(2, std::max(1 + need[n.a], need[n.b])); break;
+            case RTR_NODE_LIST:
+                u = m;
+                for (int k = 0; k < m; ++k) u = std::max(u, (m - 1 - k) + need[kids[k]]);
+                break;
+            case RTR_NODE_TRANSLATE: u = RT_FRAME_TRANSLATE + std::max(1, need[n.a]); break;
+            case RTR_NODE_ROTATE_Y: u = RT_FRAME_ROTATE + std::max(1, need[n.a]); break;
+            case RTR_NODE_FLIP_FACE: u = RT_FRAME_FLIP + std::max(1, need[n.a]); break;
+            case RTR_NODE_MEDIUM:
+                if (md) return bad(RTR_ERR_UNSUPPORTED, "constant_medium nested inside a medium boundary");
+                u = std::max(1, need[n.a]);
+                md = 1;
+                break;
+            default: break;
+            }
+            need[me] = u;
+            depth[me] = d + 1;
+            media[me] = md;
+            state[me] = 2;
+            stk.pop_back();
+        }
+        return true;
+    }
+
+    int run(rtr_scene_info* info) {
+        if (!s) return (bad(RTR_ERR_INVALID, "null scene"), code);
+        if (s->abi_version != RTR_ABI_VERSION) return (bad(RTR_ERR_INVALID, "ABI version mismatch"), code);
+        if (s->n_nodes <= 0 || s->n_list_children < 0 || s->n_materials < 0 || s->n_textures < 0 ||
+            s->n_perlin < 0 || s->n_images < 0 || s->n_lights < 0)
+            return (bad(RTR_ERR_INVALID, "negative or empty counts"), code);
+        if (!node_ix(s->root)) return (bad(RTR_ERR_INVALID, "root out of range"), code);
+        if (!s->nodes || (s->n_list_children && !s->list_children) || (s->n_materials && !s->materials) ||
+            (s->n_textures && !s->textures) || (s->n_perlin && !s->perlin) || (s->n_images && !s->images) ||
+            (s->n_image_bytes && !s->image_bytes) || (s->n_lights && !s->lights))
+            return (bad(RTR_ERR_INVALID, "null array with non-zero count"), code);
+        for (int k = 0; k < s->n_lights; ++k)
+            if (s->lights[k].type != RTR_LIGHT_QUAD)
+                return (bad(RTR_ERR_UNSUPPORTED, "only QuadLight is supported on the device"), code);
+        state.assign(s->n_nodes, 0);
+        need.assign(s->n_nodes, 0);
+        depth.assign(s->n_nodes, 0);
+        media.assign(s->n_nodes, 0);
+        if (!walk(s->root)) return code;
+        if (info) {
+            info->stack_words = std::max(1, need[s->root]);
+            info->has_media = media[s->root];
+            info->graph_depth = depth[s->root];
+            int uv = 0;
+            for (int k = 0; k < s->n_textures; ++k)
+                if (s->textures[k].type == RTR_TEX_IMAGE && s->textures[k].a >= 0) uv = 1;
+            info->needs_uv = uv;
+        }
+        return RTR_OK;
+    }
+};
+
+int params_check(rtr_context* c, const rtr_render_params* p) {
+    if (!p) return fail(c, RTR_ERR_INVALID, "null params");
+    if (p->image_width < 2 || p->image_height < 2) return fail(c, RTR_ERR_INVALID, "image smaller than 2x2");
+    if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->image_width || p->y1 > p->image_height || p->x0 >= p->x1 ||
+        p->y0 >= p->y1)
+        return fail(c, RTR_ERR_INVALID, "region outside the image or empty");
+    if (p->spp < 1 || p->max_depth < 1 || p->rr_start_depth < 0)
+        return fail(c, RTR_ERR_INVALID, "spp/max_depth/rr_start_depth out of range");
+    if (p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS)
+        return fail(c, RTR_ERR_UNSUPPORTED, "integrator id not supported (1 = RR, 4 = MIS)");
+    if (p->tile_stride > 1 && (p->tile_first < 0 || p->tile_first >= p->tile_stride))
+        return fail(c, RTR_ERR_INVALID, "tile_first must be in [0, tile_stride)");
+    if (p->spp_chunks < 0 || p->spp_chunks > p->spp) return fail(c, RTR_ERR_INVALID, "spp_chunks must be in [0, spp]");
+    if (p->pipeline < RTR_PIPELINE_AUTO || p->pipeline > RTR_PIPELINE_WAVEFRONT)
+        return fail(c, RTR_ERR_INVALID, "unknown pipeline");
+    return RTR_OK;
+}
+
+/* tiles this call owns, in the reference's dispatch order (renderer.h:40-62) */
+std::vector<int> owned_tiles(const rtr_render_params& p, int& tiles_x, int& tiles_y) {
+    tiles_x = (p.image_width + 15) / 16;
+    tiles_y = (p.image_height + 15) / 16;
+    const int stride = p.tile_stride > 1 ? p.tile_stride : 1;
+    const int first = p.tile_stride > 1 ? p.tile_first : 0;
+    std::vector<int> out;
+    for (int t = first; t < tiles_x * tiles_y; t += stride) {
+        int ty = (tiles_y - 1) - t / tiles_x, tx = t % tiles_x;
+        int xs = tx * 16, ys = ty * 16;
+        if (xs + 16 <= p.x0 || xs >= p.x1 || ys + 16 <= p.y0 || ys >= p.y1) continue;
+        out.push_back(t);
+    }
+    return out;
+}
+
+size_t stack_bytes(const rtr_context* c) { return (size_t)c->info.stack_words * RTR_BLOCK * sizeof(int); }
+
+template <typename K>
+int set_lds(rtr_context* c, K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return RTR_OK;
+}
+
+int launch_mega(rtr_context* c, const RenderK& P, int integrator) {
+    const size_t lds = stack_bytes(c);
+    const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
+    const bool media = c->info.has_media != 0;
+#define RTR_LAUNCH(I, M)                                                      \
+    do {                                                                      \
+        int rc_ = set_lds(c, k_mega<I, M>, lds);                              \
+        if (rc_) return rc_;                                                  \
+        hipLaunchKernelGGL((k_mega<I, M>), grid, block, lds, c->stream, c->ds, P); \
+    } while (0)
+    if (integrator == RTR_INTEGRATOR_MIS) {
+        if (media)
+            RTR_LAUNCH(RTR_INTEGRATOR_MIS, true);
+        else
+            RTR_LAUNCH(RTR_INTEGRATOR_MIS, false);
+    } else {
+        if (media)
+            RTR_LAUNCH(RTR_INTEGRATOR_RR, true);
+        else
+            RTR_LAUNCH(RTR_INTEGRATOR_RR, false);
+    }
+#undef RTR_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return RTR_OK;
+}
+
+int finish_stats(rtr_context* c) {
+    if (!c->stats_pending) return RTR_OK;
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    unsigned long long h[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpy(h, c->b_stats.p, sizeof h, hipMemcpyDeviceToHost));
+    c->stats.samples = h[0];
+    c->stats.closest_segments = h[1];
+    c->stats.shadow_segments = h[2];
+    c->stats.device_ms = ms;
+    c->stats_pending = false;
+    return RTR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t rtr_abi_version(void) { return RTR_ABI_VERSION; }
+
+int rtr_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return RTR_ERR_DEVICE;
+    return n;
+}
+
+uint32_t rtr_sample_seed(uint32_t seed, int32_t image_width, int32_t i, int32_t j, int32_t s) {
+    return rtr_sample_seed_inline(seed, image_width, i, j, s);
+}
+
+int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* msg, size_t msg_cap) {
+    Validator v;
+    v.s = scene;
+    int rc = v.run(info);
+    if (msg && msg_cap) {
+        std::snprintf(msg, msg_cap, "%s", v.msg.c_str());
+    }
+    return rc;
+}
+
+int rtr_create(int device_ordinal, rtr_context** out_ctx) {
+    if (!out_ctx) return fail(nullptr, RTR_ERR_INVALID, "null out_ctx");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, RTR_ERR_DEVICE,
+                    std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, RTR_ERR_INVALID, "device ordinal out of range");
+    rtr_context* c = new rtr_context();
+    c->device = device_ordinal;
+#define CREATE_CHK(expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+            delete c;                                                                        \
+            return RTR_ERR_DEVICE;                                                           \
+        }                                                                                    \
+    } while (0)
+    CREATE_CHK(hipSetDevice(device_ordinal));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreate(&c->ev0));
+    CREATE_CHK(hipEventCreate(&c->ev1));
+#undef CREATE_CHK
+    c->stream = c->own_stream;
+    int rc = ensure(c, c->b_stats, 3 * sizeof(unsigned long long));
+    if (!rc) rc = ensure(c, c->b_cancel, sizeof(int));
+    if (!rc && hipMemset(c->b_cancel.p, 0, sizeof(int)) != hipSuccess) rc = RTR_ERR_DEVICE;
+    if (rc) {
+        g_create_error = c->err;
+        rtr_destroy(c);
+        return rc;
+    }
+    *out_ctx = c;
+    return RTR_OK;
+}
+
+void rtr_destroy(rtr_context* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
+                      &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    c->pool.release();
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    if (c->side_stream) hipStreamDestroy(c->side_stream);
+    delete c;
+}
+
+int rtr_set_stream(rtr_context* c, void* hip_stream) {
+    if (!c) return RTR_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return RTR_OK;
+}
+
+int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
+    if (!c) return RTR_ERR_INVALID;
+    Validator v;
+    v.s = s;
+    rtr_scene_info info{};
+    int rc = v.run(&info);
+    if (rc) return fail(c, rc, "scene rejected: " + v.msg);
+    if ((size_t)info.stack_words * RTR_BLOCK * sizeof(int) > 160 * 1024)
+        return fail(c, RTR_ERR_UNSUPPORTED, "scene needs a deeper traversal stack than 160 KiB of LDS holds");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->has_scene = false;
+    if ((rc = upload(c, c->b_nodes, s->nodes, sizeof(rtr_node) * s->n_nodes))) return rc;
+    if ((rc = upload(c, c->b_kids, s->list_children, sizeof(int32_t) * s->n_list_children))) return rc;
+    if ((rc = upload(c, c->b_mats, s->materials, sizeof(rtr_material) * s->n_materials))) return rc;
+    if ((rc = upload(c, c->b_tex, s->textures, sizeof(rtr_texture) * s->n_textures))) return rc;
+    if ((rc = upload(c, c->b_perlin, s->perlin, sizeof(rtr_perlin) * s->n_perlin))) return rc;
+    if ((rc = upload(c, c->b_images, s->images, sizeof(rtr_image) * s->n_images))) return rc;
+    if ((rc = upload(c, c->b_imgbytes, s->image_bytes, s->n_image_bytes))) return rc;
+    if ((rc = upload(c, c->b_lights, s->lights, sizeof(rtr_light) * s->n_lights))) return rc;
+    DScene& d = c->ds;
+    d.nodes = static_cast<const rtr_node*>(c->b_nodes.p);
+    d.list_children = static_cast<const int32_t*>(c->b_kids.p);
+    d.materials = static_cast<const rtr_material*>(c->b_mats.p);
+    d.textures = static_cast<const rtr_texture*>(c->b_tex.p);
+    d.perlin = static_cast<const rtr_perlin*>(c->b_perlin.p);
+    d.images = static_cast<const rtr_image*>(c->b_images.p);
+    d.image_bytes = static_cast<const uint8_t*>(c->b_imgbytes.p);
+    d.lights = static_cast<const rtr_light*>(c->b_lights.p);
+    d.camera = s->camera;
+    for (int k = 0; k < 3; ++k) d.background[k] = s->background[k];
+    d.root = s->root;
+    d.n_nodes = s->n_nodes;
+    d.n_lights = s->n_lights;
+    d.needs_uv = info.needs_uv;
+    c->info = info;
+    c->has_scene = true;
+    return RTR_OK;
+}
+
+int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb, int64_t row_stride, int blocking) {
+    if (!c) return RTR_ERR_INVALID;
+    if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_render before rtr_upload_scene");
+    if (int prc = params_check(c, p)) return prc;
+    if (!d_rgb || row_stride < (int64_t)(p->x1 - p->x0)) return fail(c, RTR_ERR_INVALID, "bad output buffer / stride");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = finish_stats(c);
+    if (rc) return rc;
+
+    RenderK P{};
+    P.W = p->image_width, P.H = p->image_height;
+    P.x0 = p->x0, P.y0 = p->y0, P.x1 = p->x1, P.y1 = p->y1;
+    P.spp = p->spp, P.max_depth = p->max_depth, P.rr_start = p->rr_start_depth;
+    P.seed = p->seed;
+    std::vector<int> tiles = owned_tiles(*p, P.tiles_x, P.tiles_y);
+    P.n_tiles = (int)tiles.size();
+    c->stats = rtr_render_stats{};
+    if (P.n_tiles == 0) return RTR_OK;
+
+    int pipeline = p->pipeline;
+    if (pipeline == RTR_PIPELINE_AUTO) pipeline = RTR_PIPELINE_MEGAKERNEL;
+    /* auto chunking: aim for >= 4096 workgroups so the 256 CUs stay fed through the tail */
+    int chunks = p->spp_chunks;
+    if (chunks == 0) {
+        chunks = 1;
+        while (P.n_tiles * chunks < 4096 && chunks * 2 <= p->spp && chunks < 64) chunks *= 2;
+    }
+    P.chunks = chunks;
+
+    /* a cancel that arrived before this call started is stale */
+    {
+        std::lock_guard<std::mutex> lk(c->cancel_mu);
+        c->cancel_requested.store(0);
+        HIPCHK(c, hipMemsetAsync(c->b_cancel.p, 0, sizeof(int), c->stream));
+    }
+    if ((rc = upload(c, c->b_tiles, tiles.data(), tiles.size() * sizeof(int)))) return rc;
+    P.tile_ids = static_cast<const int*>(c->b_tiles.p);
+    P.stats = static_cast<unsigned long long*>(c->b_stats.p);
+    P.cancel = static_cast<const int*>(c->b_cancel.p);
+    HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, 3 * sizeof(unsigned long long), c->stream));
+
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (pipeline == RTR_PIPELINE_WAVEFRONT) {
+        int launches = 0;
+        rc = wavefront_render(c->pool, c->ds, c->info, P, p->integrator, d_rgb, row_stride, c->stream,
+                              &c->cancel_requested, &launches, c->err);
+        if (rc && rc != RTR_ERR_CANCELLED) return rc;
+        c->stats.kernel_launches = launches;
+    } else {
+        if ((rc = ensure(c, c->b_partial, (size_t)P.n_tiles * chunks * 3 * RTR_BLOCK * sizeof(double)))) return rc;
+        P.partial = static_cast<double*>(c->b_partial.p);
+        if ((rc = launch_mega(c, P, p->integrator))) return rc;
+        ResolveK R{P, d_rgb, (long long)row_stride};
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), dim3(RTR_BLOCK), 0, c->stream, R);
+        HIPCHK(c, hipGetLastError());
+        c->stats.kernel_launches = 2;
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->stats.pipeline = pipeline;
+    c->stats_pending = true;
+    if (blocking) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = finish_stats(c))) return rc;
+        if (c->cancel_requested.load()) return fail(c, RTR_ERR_CANCELLED, "render cancelled");
+    }
+    return RTR_OK;
+}
+
+int rtr_render_host(rtr_context* c, const rtr_render_params* p, double* h_rgb, int64_t row_stride) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int prc = params_check(c, p)) return prc;
+    if (!h_rgb || row_stride < (int64_t)(p->x1 - p->x0)) return fail(c, RTR_ERR_INVALID, "bad output buffer / stride");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int w = p->x1 - p->x0, h = p->y1 - p->y0;
+    const size_t bytes = (size_t)w * h * 3 * sizeof(double);
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) return fail(c, RTR_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    /* pixels of tiles this call does not own keep the caller's values */
+    hipError_t ce = hipSuccess;
+    for (int r = 0; r < h && ce == hipSuccess; ++r)
+        ce = hipMemcpyAsync(static_cast<double*>(d) + (size_t)r * w * 3, h_rgb + (size_t)r * row_stride * 3,
+                            (size_t)w * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    int rc = ce == hipSuccess ? rtr_render_device(c, p, static_cast<double*>(d), w, 1)
+                              : fail(c, RTR_ERR_DEVICE, hipGetErrorString(ce));
+    if (rc == RTR_OK || rc == RTR_ERR_CANCELLED) {
+        hipError_t e2 = hipMemcpy2D(h_rgb, (size_t)row_stride * 3 * sizeof(double), d, (size_t)w * 3 * sizeof(double),
+                                    (size_t)w * 3 * sizeof(double), h, hipMemcpyDeviceToHost);
+        if (e2 != hipSuccess) rc = fail(c, RTR_ERR_DEVICE, hipGetErrorString(e2));
+    }
+    hipFree(d);
+    return rc;
+}
+
+int rtr_synchronize(rtr_context* c) {
+    if (!c) return RTR_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTR_OK;
+}
+
+int rtr_cancel(rtr_context* c) {
+    if (!c) return RTR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(c->cancel_mu);
+    c->cancel_requested.store(1);
+    static const int one = 1;
+    hipSetDevice(c->device);
+    hipError_t e = hipMemcpyAsync(c->b_cancel.p, &one, sizeof(int), hipMemcpyHostToDevice, c->side_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->side_stream);
+    return e == hipSuccess ? RTR_OK : RTR_ERR_DEVICE;
+}
+
+int rtr_get_stats(rtr_context* c, rtr_render_stats* out) {
+    if (!c || !out) return RTR_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = finish_stats(c);
+    if (rc) return rc;
+    *out = c->stats;
+    return RTR_OK;
+}
+
+const char* rtr_last_error(const rtr_context* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+/* ---- device unit kernels (rtr_hip_test.h) ---------------------------------------------------- */
+static int test_begin(rtr_context* c, const void* recs, int64_t n, size_t rec_size) {
+    if (!c) return RTR_ERR_INVALID;
+    if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_test_* before rtr_upload_scene");
+    if (!recs || n < 0) return fail(c, RTR_ERR_INVALID, "bad record array");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return upload(c, c->b_test, recs, (size_t)n * rec_size);
+}
+static int test_end(rtr_context* c, void* recs, int64_t n, size_t rec_size) {
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCHK(c, hipMemcpy(recs, c->b_test.p, (size_t)n * rec_size, hipMemcpyDeviceToHost));
+    return RTR_OK;
+}
+static dim3 test_grid(int64_t n) { return dim3((unsigned)((n + RTR_BLOCK - 1) / RTR_BLOCK)); }
+
+int rtr_test_hits(rtr_context* c, rtr_hit_record* recs, int64_t n) {
+    int rc = test_begin(c, recs, n, sizeof *recs);
+    if (rc || n == 0) return rc;
+    DScene ds = c->ds;
+    ds.needs_uv = 1; /* the vectors pin u,v although no flattened texture of these scenes reads them */
+    auto* d = static_cast<rtr_hit_record*>(c->b_test.p);
+    const size_t lds = stack_bytes(c);
+    if (c->info.has_media) {
+        if ((rc = set_lds(c, k_test_hits<true>, lds))) return rc;
+        hipLaunchKernelGGL(k_test_hits<true>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
+    } else {
+        if ((rc = set_lds(c, k_test_hits<false>, lds))) return rc;
+        hipLaunchKernelGGL(k_test_hits<false>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
+    }
+    return test_end(c, recs, n, sizeof *recs);
+}
+
+int rtr_test_materials(rtr_context* c, rtr_mat_record* recs, int64_t n) {
+    int rc = test_begin(c, recs, n, sizeof *recs);
+    if (rc || n == 0) return rc;
+    for (int64_t k = 0; k < n; ++k)
+        if (recs[k].material < 0 || recs[k].material >= (int)(c->b_mats.cap / sizeof(rtr_material)))
+            return fail(c, RTR_ERR_INVALID, "material index out of range");
+    hipLaunchKernelGGL(k_test_materials, test_grid(n), dim3(RTR_BLOCK), 0, c->stream, c->ds,
+                       static_cast<rtr_mat_record*>(c->b_test.p), (long long)n);
+    return test_end(c, recs, n, sizeof *recs);
+}
+
+int rtr_test_lights(rtr_context* c, rtr_light_record* recs, int64_t n) {
+    int rc = test_begin(c, recs, n, sizeof *recs);
+    if (rc || n == 0) return rc;
+    for (int64_t k = 0; k < n; ++k)
+        if (recs[k].light < 0 || recs[k].light >= c->ds.n_lights) return fail(c, RTR_ERR_INVALID, "light index out of range");
+    hipLaunchKernelGGL(k_test_lights, test_grid(n), dim3(RTR_BLOCK), 0, c->stream, c->ds,
+                       static_cast<rtr_light_record*>(c->b_test.p), (long long)n);
+    return test_end(c, recs, n, sizeof *recs);
+}
+
+int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs, int64_t n) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int prc = params_check(c, p)) return prc;
+    int rc = test_begin(c, recs, n, sizeof *recs);
+    if (rc || n == 0) return rc;
+    RenderK P{};
+    P.W = p->image_width, P.H = p->image_height;
+    P.spp = p->spp, P.max_depth = p->max_depth, P.rr_start = p->rr_start_depth;
+    P.seed = p->seed;
+    auto* d = static_cast<rtr_li_record*>(c->b_test.p);
+    const size_t lds = stack_bytes(c);
+    const bool media = c->info.has_media != 0;
+#define RTR_LAUNCH(I, M)                                                                                        \
+    do {                                                                                                        \
+        if ((rc = set_lds(c, k_test_li<I, M>, lds))) return rc;                                                 \
+        hipLaunchKernelGGL((k_test_li<I, M>), test_grid(n), dim3(RTR_BLOCK), lds, c->stream, c->ds, P, d, (long long)n); \
+    } while (0)
+    if (p->integrator == RTR_INTEGRATOR_MIS) {
+        if (media)
+            RTR_LAUNCH(RTR_INTEGRATOR_MIS, true);
+        else
+            RTR_LAUNCH(RTR_INTEGRATOR_MIS, false);
+    } else {
+        if (media)
+            RTR_LAUNCH(RTR_INTEGRATOR_RR, true);
+        else
+            RTR_LAUNCH(RTR_INTEGRATOR_RR, false);
+    }
+#undef RTR_LAUNCH
+    return test_end(c, recs, n, sizeof *recs);
+}
+
+} /* extern "C" */

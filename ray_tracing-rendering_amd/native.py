@@ -1,0 +1,172 @@
+"""ctypes binding of ``librtr_hip.so`` (the C ABI of include/rtr_hip.h).
+
+There is no CPU fallback: if the library is missing or no GPU is visible, every device entry
+point raises.  The oracle under ``oracle/`` is test infrastructure and is never loaded here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+from .scene import Scene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR_UNSUPPORTED",
+           A.RTR_ERR_DEVICE: "RTR_ERR_DEVICE", A.RTR_ERR_NO_SCENE: "RTR_ERR_NO_SCENE",
+           A.RTR_ERR_CANCELLED: "RTR_ERR_CANCELLED", A.RTR_ERR_NOMEM: "RTR_ERR_NOMEM"}
+
+# every symbol include/rtr_hip.h and include/rtr_hip_test.h declare
+EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
+           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_synchronize", "rtr_cancel",
+           "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
+           "rtr_test_materials", "rtr_test_lights", "rtr_test_li")
+
+
+class SceneInfoC(C.Structure):
+    _fields_ = [("stack_words", C.c_int32), ("has_media", C.c_int32), ("needs_uv", C.c_int32),
+                ("graph_depth", C.c_int32)]
+
+
+class RtrError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (_STATUS.get(code, "rtr_status"), code, message))
+        self.code = code
+        self.message = message
+
+
+def library_path():
+    return os.path.join(_HERE, "librtr_hip.so")
+
+
+def lib():
+    """Load librtr_hip.so; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RtrError(A.RTR_ERR_DEVICE, "HIP library %s is missing: run __graft_entry__.build(); there is no "
+                       "CPU fallback" % path)
+    L = C.CDLL(path)
+    P = C.POINTER
+    vp = C.c_void_p
+    L.rtr_abi_version.restype = C.c_uint32
+    L.rtr_device_count.restype = C.c_int
+    L.rtr_create.argtypes = [C.c_int, P(vp)]
+    L.rtr_destroy.argtypes = [vp]
+    L.rtr_destroy.restype = None
+    L.rtr_set_stream.argtypes = [vp, vp]
+    L.rtr_upload_scene.argtypes = [vp, P(A.SceneDescC)]
+    L.rtr_render_device.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64, C.c_int]
+    L.rtr_render_host.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
+    L.rtr_synchronize.argtypes = [vp]
+    L.rtr_cancel.argtypes = [vp]
+    L.rtr_get_stats.argtypes = [vp, P(A.RenderStatsC)]
+    L.rtr_last_error.argtypes = [vp]
+    L.rtr_last_error.restype = C.c_char_p
+    L.rtr_sample_seed.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.rtr_sample_seed.restype = C.c_uint32
+    L.rtr_validate_scene.argtypes = [P(A.SceneDescC), P(SceneInfoC), C.c_char_p, C.c_size_t]
+    for name in ("rtr_test_hits", "rtr_test_materials", "rtr_test_lights"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64]
+    L.rtr_test_li.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
+    if L.rtr_abi_version() != A.RTR_ABI_VERSION:
+        raise RtrError(A.RTR_ERR_INVALID, "librtr_hip.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def validate_scene(scene):
+    """Host-only scene check (no GPU needed).  Returns the scene facts; raises RtrError."""
+    L = lib()
+    d = scene.desc()
+    info = SceneInfoC()
+    msg = C.create_string_buffer(256)
+    rc = L.rtr_validate_scene(C.byref(d), C.byref(info), msg, len(msg))
+    if rc != 0:
+        raise RtrError(rc, msg.value.decode())
+    return {"stack_words": info.stack_words, "has_media": bool(info.has_media), "needs_uv": bool(info.needs_uv),
+            "graph_depth": info.graph_depth}
+
+
+class Context:
+    """One GPU.  Mirrors the life cycle of the reference's ``Renderer`` object
+    (renderer/renderer.h:22-28): create, give it a scene, render, cancel."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.rtr_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RtrError(rc, self._L.rtr_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.scene = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rtr_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RtrError(rc, self._L.rtr_last_error(self._h).decode())
+
+    def set_stream(self, stream_handle):
+        """Run the kernels on an existing hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        self._chk(self._L.rtr_set_stream(self._h, C.c_void_p(stream_handle or None)))
+
+    def upload(self, scene):
+        if not isinstance(scene, Scene):
+            raise TypeError("expected a flattened Scene")
+        d = scene.desc()
+        self._chk(self._L.rtr_upload_scene(self._h, C.byref(d)))
+        self.scene = scene
+
+    def render_into(self, params, device_ptr, row_stride, blocking=False):
+        """Linear mean radiance of params' region into a device buffer of doubles."""
+        self._chk(self._L.rtr_render_device(self._h, C.byref(params), C.c_void_p(device_ptr), int(row_stride),
+                                            1 if blocking else 0))
+
+    def render(self, params):
+        """Blocking render to a host array (H, W, 3) of the region (includes the D2H copy)."""
+        h, w = params.y1 - params.y0, params.x1 - params.x0
+        out = np.zeros((h, w, 3), dtype=np.float64)
+        self._chk(self._L.rtr_render_host(self._h, C.byref(params), out.ctypes.data, w))
+        return out
+
+    def synchronize(self):
+        self._chk(self._L.rtr_synchronize(self._h))
+
+    def cancel(self):
+        self._chk(self._L.rtr_cancel(self._h))
+
+    def stats(self):
+        s = A.RenderStatsC()
+        self._chk(self._L.rtr_get_stats(self._h, C.byref(s)))
+        return {"samples": s.samples, "closest_segments": s.closest_segments, "shadow_segments": s.shadow_segments,
+                "device_ms": s.device_ms, "kernel_launches": s.kernel_launches, "pipeline": s.pipeline}
+
+    # device unit kernels over golden-vector records (include/rtr_hip_test.h)
+    def test_records(self, kind, recs, params=None):
+        out = np.ascontiguousarray(recs.copy())
+        fn = getattr(self._L, "rtr_test_" + kind)
+        if kind == "li":
+            self._chk(fn(self._h, C.byref(params), out.ctypes.data, len(out)))
+        else:
+            self._chk(fn(self._h, out.ctypes.data, len(out)))
+        return out
