@@ -1,8 +1,29 @@
 /*
- * rt_wavefront.h -- wavefront pipeline (SoA path pool in HBM; extend / shade / connect
- * stage kernels).  Placeholder until the stages land: the entry point reports
- * RTR_ERR_UNSUPPORTED so RTR_PIPELINE_WAVEFRONT fails loudly instead of silently
- * running something else.
+ * rt_wavefront.h -- the wavefront pipeline: the integrator loop of
+ * renderer/mis_path_integrator.h:25-150 (and rr_path_integrator.h:21-59) cut at its two
+ * ray casts into stage kernels that exchange path state through SoA arrays in HBM.
+ *
+ * Path pool.  Slot = (owned tile, spp chunk, pixel of the tile): the same numbering as the
+ * megakernel's (blockIdx, threadIdx).  A slot runs the samples of its chunk back to back
+ * (in-slot regeneration), so per-pixel sums keep the sample order of renderer.h:72-79 and
+ * the pool stays full until slots run out of samples.  Every array below is indexed by
+ * slot, so consecutive lanes touch consecutive 8-byte words (coalesced 512 B per wave).
+ *
+ * One iteration (one bounce of every live path):
+ *   wf_extend   flush a finished sample into the pixel sum, start the next camera sample
+ *               (renderer.h:73-75), cast the closest-hit ray (mis_path_integrator.h:37),
+ *               handle the miss, else store the hit and append the slot to the queue of its
+ *               material type  -> material-sorted shading waves.
+ *   wf_shade    over the concatenated material queues: emission + MIS weight, light sample
+ *               (:72-103,191-229), BSDF sample, throughput, Russian roulette (:105-146);
+ *               writes the next ray and, if the light sample is usable, a shadow request.
+ *   wf_connect  over the shadow queue: occlusion ray (:210-213); unoccluded -> L += contrib.
+ * Scenes with participating media draw random numbers INSIDE both ray casts
+ * (constant_medium.h:85), so there the shade stage is split around the connect stage
+ * (wf_shade_a, wf_connect, wf_shade_b) to keep the reference's draw order.
+ *
+ * Queue counters are double-buffered by iteration parity: wf_extend of iteration i clears
+ * the counters of parity (i+1)&1, which no kernel of iteration i touches.
  */
 #pragma once
 
@@ -12,12 +33,420 @@
 #include <atomic>
 #include <string>
 
+#define WF_NTYPES RTR_MAT_TYPE_COUNT
+
+enum { WF_DONE = 0, WF_NEED_SAMPLE = 1, WF_HIT = 2, WF_CONTINUE = 3 };
+/* flags word: bits 0-1 status, bit 2 specular_bounce, bit 3 "no sample yet", bits 8.. depth */
+#define WF_STATUS(f) ((f) & 3)
+#define WF_SPEC 4
+#define WF_FIRST 8
+
+struct WfState {
+    /* ray */
+    double *ox, *oy, *oz, *dx, *dy, *dz, *tm;
+    /* path */
+    double *tx, *ty, *tz, *lx, *ly, *lz, *ax, *ay, *az, *pdf;
+    uint32_t* rng;
+    int32_t* samp;
+    int32_t* flags;
+    /* hit record */
+    double *ht, *hpx, *hpy, *hpz, *hnx, *hny, *hnz, *hu, *hv;
+    int32_t* hmat; /* material | front_face << 30 */
+    /* shadow request */
+    double *swx, *swy, *swz, *stmax, *scx, *scy, *scz;
+    /* queues */
+    int32_t* q_mat;    /* [WF_NTYPES][n_slots] */
+    int32_t* q_shadow; /* [n_slots] */
+    uint32_t* counters; /* [2][WF_NTYPES + 2]: per parity: material queue sizes, shadow queue size, pad */
+    uint32_t* n_live;   /* slots not yet WF_DONE */
+    int n_slots;
+};
+#define WF_CNT_STRIDE (WF_NTYPES + 2)
+
 struct WavefrontPool {
-    void release() {}
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    uint32_t* h_live = nullptr; /* pinned */
+    void release() {
+        if (slab) (void)hipFree(slab);
+        if (h_live) (void)hipHostFree(h_live);
+        slab = nullptr, slab_bytes = 0, h_live = nullptr;
+    }
 };
 
-inline int wavefront_render(WavefrontPool&, const DScene&, const rtr_scene_info&, const RenderK&, int, double*,
-                            int64_t, hipStream_t, std::atomic<int>*, int*, std::string& err) {
-    err = "wavefront pipeline not built into this library";
-    return RTR_ERR_UNSUPPORTED;
+RT_DEV V3 ldv(const double* x, const double* y, const double* z, int i) { return mk(x[i], y[i], z[i]); }
+RT_DEV void stv(double* x, double* y, double* z, int i, V3 v) { x[i] = v.x, y[i] = v.y, z[i] = v.z; }
+
+/* slot -> pixel (same layout as k_mega) */
+RT_DEV void slot_pixel(const RenderK& P, int slot, int& i, int& j, int& chunk, bool& active) {
+    const int blk = slot / RTR_BLOCK, tid = slot % RTR_BLOCK;
+    chunk = blk % P.chunks;
+    tile_pixel(P, blk / P.chunks, tid, i, j, active);
+}
+
+__global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const RenderK P) {
+    const int slot = blockIdx.x * RTR_BLOCK + threadIdx.x;
+    if (slot >= S.n_slots) return;
+    int i, j, chunk;
+    bool active;
+    slot_pixel(P, slot, i, j, chunk, active);
+    const int s0 = (int)((long long)chunk * P.spp / P.chunks);
+    const int s1 = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+    active = active && s0 < s1;
+    S.ax[slot] = 0, S.ay[slot] = 0, S.az[slot] = 0;
+    S.lx[slot] = 0, S.ly[slot] = 0, S.lz[slot] = 0;
+    S.samp[slot] = s0 - 1;
+    S.flags[slot] = active ? (WF_NEED_SAMPLE | WF_FIRST) : WF_DONE;
+    if (!active) { /* pixels outside the region still own a partial-sum cell */
+        double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
+        out[0] = 0, out[RTR_BLOCK] = 0, out[2 * RTR_BLOCK] = 0;
+    }
+    const unsigned long long live = wave_sum(active ? 1ull : 0ull);
+    if ((threadIdx.x & 63) == 0 && live) atomicAdd(S.n_live, (uint32_t)live);
+    if (slot < 2 * WF_CNT_STRIDE) S.counters[slot] = 0;
+}
+
+template <bool MEDIA>
+__global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const WfState S, const RenderK P,
+                                                       const int parity) {
+    extern __shared__ int lds_stack[];
+    const Stack st{lds_stack + threadIdx.x};
+    if (blockIdx.x == 0 && threadIdx.x < WF_CNT_STRIDE) S.counters[(parity ^ 1) * WF_CNT_STRIDE + threadIdx.x] = 0;
+    uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
+    unsigned n_closest = 0, n_samples = 0, n_done = 0;
+    for (int slot = blockIdx.x * RTR_BLOCK + threadIdx.x; slot < S.n_slots; slot += gridDim.x * RTR_BLOCK) {
+        int flags = S.flags[slot];
+        int status = WF_STATUS(flags);
+        if (status == WF_DONE) continue;
+        V3 ro, rd;
+        Real tm;
+        uint32_t rng;
+        if (status == WF_NEED_SAMPLE) {
+            int i, j, chunk;
+            bool active;
+            slot_pixel(P, slot, i, j, chunk, active);
+            V3 acc = ldv(S.ax, S.ay, S.az, slot);
+            if (!(flags & WF_FIRST)) { /* renderer.h:77-78: pixel_color += Li */
+                acc = add(acc, ldv(S.lx, S.ly, S.lz, slot));
+                ++n_samples;
+            }
+            const int s = S.samp[slot] + 1;
+            const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+            if (s >= s_end) {
+                S.flags[slot] = WF_DONE;
+                double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
+                out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
+                ++n_done;
+                continue;
+            }
+            stv(S.ax, S.ay, S.az, slot, acc);
+            S.samp[slot] = s;
+            rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
+            const Real u = (i + rng_next(rng)) / (P.W - 1);
+            const Real v = (j + rng_next(rng)) / (P.H - 1);
+            camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
+            stv(S.ox, S.oy, S.oz, slot, ro);
+            stv(S.dx, S.dy, S.dz, slot, rd);
+            S.tm[slot] = tm;
+            stv(S.tx, S.ty, S.tz, slot, mk(1.0, 1.0, 1.0));
+            stv(S.lx, S.ly, S.lz, slot, mk(0.0, 0.0, 0.0));
+            S.pdf[slot] = 0.0;
+            flags = 0; /* depth 0, not specular */
+        } else {
+            ro = ldv(S.ox, S.oy, S.oz, slot);
+            rd = ldv(S.dx, S.dy, S.dz, slot);
+            tm = S.tm[slot];
+            rng = S.rng[slot];
+            flags &= ~3;
+        }
+        Hit rec;
+        rec.u = 0, rec.v = 0;
+        Real tmax = RT_INF;
+        ++n_closest;
+        if (!traverse<true, MEDIA>(sc, sc.root, ro, rd, tm, 0.001, tmax, rec, rng, st, 0)) {
+            /* mis_path_integrator.h:48-49, rr_path_integrator.h:31-33 */
+            V3 L = add(ldv(S.lx, S.ly, S.lz, slot), mul(ldv(S.tx, S.ty, S.tz, slot), ld3(sc.background)));
+            stv(S.lx, S.ly, S.lz, slot, L);
+            S.flags[slot] = flags | WF_NEED_SAMPLE;
+            S.rng[slot] = rng;
+            continue;
+        }
+        S.ht[slot] = rec.t;
+        stv(S.hpx, S.hpy, S.hpz, slot, rec.p);
+        stv(S.hnx, S.hny, S.hnz, slot, rec.n);
+        if (sc.needs_uv) S.hu[slot] = rec.u, S.hv[slot] = rec.v;
+        S.hmat[slot] = rec.mat | (rec.front ? (1 << 30) : 0);
+        S.flags[slot] = flags | WF_HIT;
+        S.rng[slot] = rng;
+        const int type = sc.materials[rec.mat].type;
+        const uint32_t at = atomicAdd(&cnt[type], 1u);
+        S.q_mat[(size_t)type * S.n_slots + at] = slot;
+    }
+    const unsigned long long a = wave_sum(n_samples), b = wave_sum(n_closest), d = wave_sum(n_done);
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&P.stats[0], a);
+        if (b) atomicAdd(&P.stats[1], b);
+        if (d) atomicSub(S.n_live, (uint32_t)d);
+    }
+}
+
+/* k-th entry of the concatenated material queues */
+RT_DEV int wf_sorted_slot(const WfState& S, const uint32_t* cnt, uint32_t k) {
+#pragma unroll
+    for (int t = 0; t < WF_NTYPES; ++t) {
+        const uint32_t c = cnt[t];
+        if (k < c) return S.q_mat[(size_t)t * S.n_slots + k];
+        k -= c;
+    }
+    return -1;
+}
+
+RT_DEV void wf_load_hit(const DScene& sc, const WfState& S, int slot, Hit& rec) {
+    rec.t = S.ht[slot];
+    rec.p = ldv(S.hpx, S.hpy, S.hpz, slot);
+    rec.n = ldv(S.hnx, S.hny, S.hnz, slot);
+    rec.u = 0, rec.v = 0;
+    if (sc.needs_uv) rec.u = S.hu[slot], rec.v = S.hv[slot];
+    const int m = S.hmat[slot];
+    rec.mat = m & ~(1 << 30);
+    rec.front = (m >> 30) & 1;
+}
+
+RT_DEV void wf_load_path(const WfState& S, int slot, int flags, PathState& ps) {
+    ps.ro = ldv(S.ox, S.oy, S.oz, slot);
+    ps.rd = ldv(S.dx, S.dy, S.dz, slot);
+    ps.tm = S.tm[slot];
+    ps.thr = ldv(S.tx, S.ty, S.tz, slot);
+    ps.L = ldv(S.lx, S.ly, S.lz, slot);
+    ps.prev_bsdf_pdf = S.pdf[slot];
+    ps.depth = flags >> 8;
+    ps.specular_bounce = (flags & WF_SPEC) != 0;
+}
+
+/* after shade_b / shade_rr: store the continued path or mark the sample finished */
+RT_DEV void wf_store_path(const WfState& S, int slot, const PathState& ps, bool go, int max_depth) {
+    int depth = ps.depth;
+    if (go) {
+        stv(S.ox, S.oy, S.oz, slot, ps.ro);
+        stv(S.dx, S.dy, S.dz, slot, ps.rd);
+        stv(S.tx, S.ty, S.tz, slot, ps.thr);
+        S.pdf[slot] = ps.prev_bsdf_pdf;
+        go = ++depth < max_depth;
+    }
+    S.flags[slot] = (go ? WF_CONTINUE : WF_NEED_SAMPLE) | (ps.specular_bounce ? WF_SPEC : 0) | (depth << 8);
+}
+
+RT_DEV void wf_push_shadow(const WfState& S, uint32_t* cnt, int slot, const ShadowReq& rq) {
+    stv(S.swx, S.swy, S.swz, slot, rq.wi);
+    S.stmax[slot] = rq.tmax;
+    stv(S.scx, S.scy, S.scz, slot, rq.contrib);
+    const uint32_t at = atomicAdd(&cnt[WF_NTYPES], 1u);
+    S.q_shadow[at] = slot;
+}
+
+/* PHASE 0: whole shading (no media).  PHASE 1: first half only (emission + light sample).
+ * PHASE 2: second half only (BSDF sample + roulette), after the connect stage. */
+template <int INTEG, int PHASE>
+__global__ void __launch_bounds__(RTR_BLOCK) wf_shade(const DScene sc, const WfState S, const RenderK P,
+                                                      const int parity) {
+    uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
+    uint32_t total = 0;
+#pragma unroll
+    for (int t = 0; t < WF_NTYPES; ++t) total += cnt[t];
+    for (uint32_t k = blockIdx.x * RTR_BLOCK + threadIdx.x; k < total; k += gridDim.x * RTR_BLOCK) {
+        const int slot = wf_sorted_slot(S, cnt, k);
+        const int flags = S.flags[slot];
+        Hit rec;
+        wf_load_hit(sc, S, slot, rec);
+        PathState ps;
+        wf_load_path(S, slot, flags, ps);
+        uint32_t rng = S.rng[slot];
+        bool go;
+        if (INTEG == RTR_INTEGRATOR_MIS) {
+            const V3 wo = neg(unit(ps.rd));
+            if (PHASE != 2) {
+                const V3 L0 = ps.L;
+                ShadowReq rq;
+                shade_a_mis(sc, ps, rec, wo, rng, rq);
+                if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
+                if (rq.valid) wf_push_shadow(S, cnt, slot, rq);
+            }
+            if (PHASE == 1) {
+                S.rng[slot] = rng;
+                continue;
+            }
+            go = shade_b_mis(sc, ps, rec, wo, rng, P.rr_start);
+        } else {
+            const V3 L0 = ps.L;
+            go = shade_rr(sc, ps, rec, rng, P.rr_start);
+            if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
+        }
+        wf_store_path(S, slot, ps, go, P.max_depth);
+        S.rng[slot] = rng;
+    }
+}
+
+template <bool MEDIA>
+__global__ void __launch_bounds__(RTR_BLOCK) wf_connect(const DScene sc, const WfState S, const RenderK P,
+                                                        const int parity) {
+    extern __shared__ int lds_stack[];
+    const Stack st{lds_stack + threadIdx.x};
+    const uint32_t total = S.counters[parity * WF_CNT_STRIDE + WF_NTYPES];
+    unsigned n_shadow = 0;
+    for (uint32_t k = blockIdx.x * RTR_BLOCK + threadIdx.x; k < total; k += gridDim.x * RTR_BLOCK) {
+        const int slot = S.q_shadow[k];
+        /* shadow_ray origin = rec.p (mis_path_integrator.h:210); the hit record outlives the shade stage */
+        const V3 o = ldv(S.hpx, S.hpy, S.hpz, slot);
+        const V3 wi = ldv(S.swx, S.swy, S.swz, slot);
+        Real tmax = S.stmax[slot];
+        uint32_t rng = MEDIA ? S.rng[slot] : 1u;
+        Hit dummy;
+        ++n_shadow;
+        const bool hit = traverse<false, MEDIA>(sc, sc.root, o, wi, 0.0, 0.001, tmax, dummy, rng, st, 0);
+        if (MEDIA) S.rng[slot] = rng;
+        if (!hit) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
+    }
+    const unsigned long long c = wave_sum(n_shadow);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[2], c);
+}
+
+/* ---- host driver ------------------------------------------------------------------------------ */
+inline int wf_fail(std::string& err, int code, const std::string& m) {
+    err = m;
+    return code;
+}
+#define WF_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return wf_fail(err, RTR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, std::string& err) {
+    const size_t n = (size_t)n_slots;
+    const size_t n_f64 = 7 + 10 + 9 + 7; /* ray, path, hit, shadow */
+    const size_t bytes = n_f64 * n * 8 + 4 * n * 4 /* rng samp flags hmat */ + (size_t)WF_NTYPES * n * 4 + n * 4 +
+                         (2 * WF_CNT_STRIDE + 2) * 4 + 256;
+    if (pool.slab_bytes < bytes) {
+        if (pool.slab) WF_HIP(hipFree(pool.slab));
+        pool.slab = nullptr, pool.slab_bytes = 0;
+        hipError_t e = hipMalloc(&pool.slab, bytes);
+        if (e != hipSuccess) return wf_fail(err, RTR_ERR_NOMEM, std::string("hipMalloc(path pool): ") + hipGetErrorString(e));
+        pool.slab_bytes = bytes;
+    }
+    if (!pool.h_live) WF_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.h_live), 64, hipHostMallocDefault));
+    char* p = static_cast<char*>(pool.slab);
+    auto f64 = [&]() {
+        double* r = reinterpret_cast<double*>(p);
+        p += n * 8;
+        return r;
+    };
+    double** arrs[] = {&S.ox, &S.oy, &S.oz, &S.dx, &S.dy, &S.dz, &S.tm, &S.tx, &S.ty, &S.tz, &S.lx,
+                       &S.ly, &S.lz, &S.ax, &S.ay, &S.az, &S.pdf, &S.ht, &S.hpx, &S.hpy, &S.hpz, &S.hnx,
+                       &S.hny, &S.hnz, &S.hu, &S.hv, &S.swx, &S.swy, &S.swz, &S.stmax, &S.scx, &S.scy, &S.scz};
+    static_assert(sizeof(arrs) / sizeof(arrs[0]) == 33, "array count");
+    for (double** a : arrs) *a = f64();
+    auto i32 = [&](size_t count) {
+        int32_t* r = reinterpret_cast<int32_t*>(p);
+        p += count * 4;
+        return r;
+    };
+    S.rng = reinterpret_cast<uint32_t*>(i32(n));
+    S.samp = i32(n);
+    S.flags = i32(n);
+    S.hmat = i32(n);
+    S.q_mat = i32((size_t)WF_NTYPES * n);
+    S.q_shadow = i32(n);
+    S.counters = reinterpret_cast<uint32_t*>(i32(2 * WF_CNT_STRIDE));
+    S.n_live = reinterpret_cast<uint32_t*>(i32(2));
+    S.n_slots = n_slots;
+    return RTR_OK;
+}
+
+template <typename K>
+inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
+    if (bytes > 64 * 1024)
+        WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)bytes));
+    return RTR_OK;
+}
+
+/* Runs the whole render on `stream` and returns when it has finished (the iteration loop is
+ * driven from the host, which polls the live-slot counter every `check` iterations). */
+inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const rtr_scene_info& info, const RenderK& Pin,
+                            int integrator, double* d_rgb, int64_t row_stride, hipStream_t stream,
+                            std::atomic<int>* cancel, int* launches, std::string& err) {
+    RenderK P = Pin;
+    const long long n_slots_ll = (long long)P.n_tiles * P.chunks * RTR_BLOCK;
+    if (n_slots_ll > (1ll << 30)) return wf_fail(err, RTR_ERR_UNSUPPORTED, "path pool larger than 2^30 slots");
+    WfState S{};
+    int rc = wf_alloc(pool, S, (int)n_slots_ll, err);
+    if (rc) return rc;
+    const size_t lds = (size_t)info.stack_words * RTR_BLOCK * sizeof(int);
+    const bool media = info.has_media != 0;
+    const bool mis = integrator == RTR_INTEGRATOR_MIS;
+    if ((rc = wf_lds_attr(wf_extend<true>, lds, err)) || (rc = wf_lds_attr(wf_extend<false>, lds, err)) ||
+        (rc = wf_lds_attr(wf_connect<true>, lds, err)) || (rc = wf_lds_attr(wf_connect<false>, lds, err)))
+        return rc;
+    const dim3 block(RTR_BLOCK);
+    const int n_blocks = (S.n_slots + RTR_BLOCK - 1) / RTR_BLOCK;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)cus;
+    const dim3 grid((unsigned)n_blocks); /* one slot per lane; kernels keep the grid-stride form */
+    int n_launch = 0;
+    WF_HIP(hipMemsetAsync(S.n_live, 0, 8, stream));
+    hipLaunchKernelGGL(wf_init, dim3((unsigned)n_blocks), block, 0, stream, S, P);
+    ++n_launch;
+    const bool has_lights = sc.n_lights > 0;
+    int iter = 0;
+    const int check = 32;
+    bool cancelled = false;
+    for (;;) {
+        for (int b = 0; b < check; ++b, ++iter) {
+            const int par = iter & 1;
+            if (media)
+                hipLaunchKernelGGL(wf_extend<true>, grid, block, lds, stream, sc, S, P, par);
+            else
+                hipLaunchKernelGGL(wf_extend<false>, grid, block, lds, stream, sc, S, P, par);
+            ++n_launch;
+            if (!mis) {
+                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_RR, 0>), grid, block, 0, stream, sc, S, P, par);
+                ++n_launch;
+            } else if (!media) {
+                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 0>), grid, block, 0, stream, sc, S, P, par);
+                ++n_launch;
+                if (has_lights) {
+                    hipLaunchKernelGGL(wf_connect<false>, grid, block, lds, stream, sc, S, P, par);
+                    ++n_launch;
+                }
+            } else {
+                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 1>), grid, block, 0, stream, sc, S, P, par);
+                if (has_lights) {
+                    hipLaunchKernelGGL(wf_connect<true>, grid, block, lds, stream, sc, S, P, par);
+                    ++n_launch;
+                }
+                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 2>), grid, block, 0, stream, sc, S, P, par);
+                n_launch += 2;
+            }
+        }
+        WF_HIP(hipGetLastError());
+        WF_HIP(hipMemcpyAsync(pool.h_live, S.n_live, 4, hipMemcpyDeviceToHost, stream));
+        WF_HIP(hipStreamSynchronize(stream));
+        if (*pool.h_live == 0) break;
+        if (cancel && cancel->load()) {
+            cancelled = true;
+            break;
+        }
+    }
+    if (cancelled) { /* unfinished pixels have no sum yet: leave the caller's buffer untouched */
+        if (launches) *launches = n_launch;
+        return RTR_ERR_CANCELLED;
+    }
+    ResolveK R{P, d_rgb, (long long)row_stride};
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), block, 0, stream, R);
+    ++n_launch;
+    WF_HIP(hipGetLastError());
+    if (launches) *launches = n_launch;
+    return RTR_OK;
 }

@@ -510,16 +510,17 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     P.cancel = static_cast<const int*>(c->b_cancel.p);
     HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, 3 * sizeof(unsigned long long), c->stream));
 
+    if ((rc = ensure(c, c->b_partial, (size_t)P.n_tiles * chunks * 3 * RTR_BLOCK * sizeof(double)))) return rc;
+    P.partial = static_cast<double*>(c->b_partial.p);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
         rc = wavefront_render(c->pool, c->ds, c->info, P, p->integrator, d_rgb, row_stride, c->stream,
                               &c->cancel_requested, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
+        if (rc == RTR_ERR_CANCELLED) c->cancel_requested.store(1);
         c->stats.kernel_launches = launches;
     } else {
-        if ((rc = ensure(c, c->b_partial, (size_t)P.n_tiles * chunks * 3 * RTR_BLOCK * sizeof(double)))) return rc;
-        P.partial = static_cast<double*>(c->b_partial.p);
         if ((rc = launch_mega(c, P, p->integrator))) return rc;
         ResolveK R{P, d_rgb, (long long)row_stride};
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), dim3(RTR_BLOCK), 0, c->stream, R);
