@@ -84,6 +84,27 @@ RT_DEV void slot_pixel(const RenderK& P, int slot, int& i, int& j, int& chunk, b
     tile_pixel(P, blk / P.chunks, tid, i, j, active);
 }
 
+/* Append this block's items to global queues with ONE global atomic per queue per block:
+ * lanes take a position inside the block with an LDS atomic, a leader reserves the block's
+ * range, then every lane writes its slot.  (One global atomic per lane on a single counter
+ * serialises at ~11 ns each on MI355X and dominated the first version of this pipeline.)
+ * Must be called by all threads of the block; `q` < 0 means "nothing to append". */
+template <int NQ>
+RT_DEV void wf_block_append(uint32_t* lds_cnt /* [2*NQ] */, uint32_t* gcnt, int32_t* qbase, size_t qstride, int q,
+                            int slot) {
+    if (threadIdx.x < 2 * NQ) lds_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t pos = 0;
+    if (q >= 0) pos = atomicAdd(&lds_cnt[q], 1u);
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const uint32_t c = lds_cnt[threadIdx.x];
+        if (c) lds_cnt[NQ + threadIdx.x] = atomicAdd(&gcnt[threadIdx.x], c);
+    }
+    __syncthreads();
+    if (q >= 0) qbase[(size_t)q * qstride + lds_cnt[NQ + q] + pos] = slot;
+}
+
 __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const RenderK P) {
     const int slot = blockIdx.x * RTR_BLOCK + threadIdx.x;
     if (slot >= S.n_slots) return;
@@ -114,10 +135,15 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const Wf
     if (blockIdx.x == 0 && threadIdx.x < WF_CNT_STRIDE) S.counters[(parity ^ 1) * WF_CNT_STRIDE + threadIdx.x] = 0;
     uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
     unsigned n_closest = 0, n_samples = 0, n_done = 0;
-    for (int slot = blockIdx.x * RTR_BLOCK + threadIdx.x; slot < S.n_slots; slot += gridDim.x * RTR_BLOCK) {
+    __shared__ uint32_t lds_cnt[2 * WF_NTYPES];
+    for (int base = blockIdx.x * RTR_BLOCK; base < S.n_slots; base += gridDim.x * RTR_BLOCK) {
+        const int slot = base + threadIdx.x;
+        int qtype = -1;
+        do {
+        if (slot >= S.n_slots) break;
         int flags = S.flags[slot];
         int status = WF_STATUS(flags);
-        if (status == WF_DONE) continue;
+        if (status == WF_DONE) break;
         V3 ro, rd;
         Real tm;
         uint32_t rng;
@@ -137,7 +163,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const Wf
                 double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
                 out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
                 ++n_done;
-                continue;
+                break;
             }
             stv(S.ax, S.ay, S.az, slot, acc);
             S.samp[slot] = s;
@@ -169,7 +195,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const Wf
             stv(S.lx, S.ly, S.lz, slot, L);
             S.flags[slot] = flags | WF_NEED_SAMPLE;
             S.rng[slot] = rng;
-            continue;
+            break;
         }
         S.ht[slot] = rec.t;
         stv(S.hpx, S.hpy, S.hpz, slot, rec.p);
@@ -178,9 +204,9 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const Wf
         S.hmat[slot] = rec.mat | (rec.front ? (1 << 30) : 0);
         S.flags[slot] = flags | WF_HIT;
         S.rng[slot] = rng;
-        const int type = sc.materials[rec.mat].type;
-        const uint32_t at = atomicAdd(&cnt[type], 1u);
-        S.q_mat[(size_t)type * S.n_slots + at] = slot;
+        qtype = sc.materials[rec.mat].type;
+        } while (false);
+        wf_block_append<WF_NTYPES>(lds_cnt, cnt, S.q_mat, (size_t)S.n_slots, qtype, slot);
     }
     const unsigned long long a = wave_sum(n_samples), b = wave_sum(n_closest), d = wave_sum(n_done);
     if ((threadIdx.x & 63) == 0) {
@@ -236,12 +262,10 @@ RT_DEV void wf_store_path(const WfState& S, int slot, const PathState& ps, bool 
     S.flags[slot] = (go ? WF_CONTINUE : WF_NEED_SAMPLE) | (ps.specular_bounce ? WF_SPEC : 0) | (depth << 8);
 }
 
-RT_DEV void wf_push_shadow(const WfState& S, uint32_t* cnt, int slot, const ShadowReq& rq) {
+RT_DEV void wf_store_shadow(const WfState& S, int slot, const ShadowReq& rq) {
     stv(S.swx, S.swy, S.swz, slot, rq.wi);
     S.stmax[slot] = rq.tmax;
     stv(S.scx, S.scy, S.scz, slot, rq.contrib);
-    const uint32_t at = atomicAdd(&cnt[WF_NTYPES], 1u);
-    S.q_shadow[at] = slot;
 }
 
 /* PHASE 0: whole shading (no media).  PHASE 1: first half only (emission + light sample).
@@ -250,11 +274,17 @@ template <int INTEG, int PHASE>
 __global__ void __launch_bounds__(RTR_BLOCK) wf_shade(const DScene sc, const WfState S, const RenderK P,
                                                       const int parity) {
     uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
+    __shared__ uint32_t lds_cnt[2];
     uint32_t total = 0;
 #pragma unroll
     for (int t = 0; t < WF_NTYPES; ++t) total += cnt[t];
-    for (uint32_t k = blockIdx.x * RTR_BLOCK + threadIdx.x; k < total; k += gridDim.x * RTR_BLOCK) {
-        const int slot = wf_sorted_slot(S, cnt, k);
+    for (uint32_t base = blockIdx.x * RTR_BLOCK; base < total; base += gridDim.x * RTR_BLOCK) {
+        const uint32_t k = base + threadIdx.x;
+        int slot = -1;
+        int want_shadow = -1;
+        do {
+        if (k >= total) break;
+        slot = wf_sorted_slot(S, cnt, k);
         const int flags = S.flags[slot];
         Hit rec;
         wf_load_hit(sc, S, slot, rec);
@@ -269,11 +299,14 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_shade(const DScene sc, const WfS
                 ShadowReq rq;
                 shade_a_mis(sc, ps, rec, wo, rng, rq);
                 if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
-                if (rq.valid) wf_push_shadow(S, cnt, slot, rq);
+                if (rq.valid) {
+                    wf_store_shadow(S, slot, rq);
+                    want_shadow = 0;
+                }
             }
             if (PHASE == 1) {
                 S.rng[slot] = rng;
-                continue;
+                break;
             }
             go = shade_b_mis(sc, ps, rec, wo, rng, P.rr_start);
         } else {
@@ -283,6 +316,9 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_shade(const DScene sc, const WfS
         }
         wf_store_path(S, slot, ps, go, P.max_depth);
         S.rng[slot] = rng;
+        } while (false);
+        if (INTEG == RTR_INTEGRATOR_MIS && PHASE != 2)
+            wf_block_append<1>(lds_cnt, cnt + WF_NTYPES, S.q_shadow, 0, want_shadow, slot);
     }
 }
 

@@ -1,0 +1,83 @@
+"""Multi-GPU path on CPU: tile ownership (renderer.h:40-62 numbering) and the host-side
+framebuffer gather over a world_size-2 gloo job.  The per-rank renderer is injected; here it is
+the CPU oracle (test infrastructure), on the GPU box bench.py uses the HIP context."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import _golden as G
+
+A = G.A
+rtr = G.rtr
+
+
+@pytest.mark.parametrize("w,h,world", [(800, 800, 8), (40, 27, 3), (1920, 1080, 4), (17, 16, 2)])
+def test_tiles_partition(w, h, world):
+    seen = []
+    for r in range(world):
+        seen += rtr.renderer.tiles_of_rank(w, h, r, world)
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    assert sorted(seen) == list(range(tx * ty))
+    cover = sum(rtr.renderer.ownership_mask(w, h, r, world).astype(int) for r in range(world))
+    assert np.all(cover == 1)
+
+
+def test_tile_order_is_top_row_first():
+    # renderer.h:61-62: tile 0 is the top-left tile (largest y)
+    assert rtr.renderer.tile_rect(64, 48, 0) == (0, 32, 16, 48)
+    assert rtr.renderer.tile_rect(64, 48, 5) == (16, 16, 32, 32)
+    assert rtr.renderer.tile_rect(40, 27, 2) == (32, 16, 40, 27)
+
+
+def test_render_buffer_store_matches_reference_output_stage():
+    rb = rtr.RenderBuffer(4, 2)
+    lin = np.array([[[0.25, 4.0, 0.0]] * 4] * 2)
+    rb.store_linear(lin)
+    assert np.allclose(rb.get_data()[0, 0], [0.5, 1.0, 0.0])  # sqrt gamma, clamp (renderer.h:126-140)
+    assert rb.to_rgb8()[0, 0].tolist() == [127, 255, 0]        # uchar(c * 255) truncation (render_buffer.h:44-49)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = G.scene(21)
+        W, H, spp = 40, 40, 2
+
+        def render_fn(first, stride):  # oracle stands in for the GPU here
+            out = np.full((H, W, 3), -1.0)
+            p = A.make_params(W, H, spp, seed=11, tile_first=first, tile_stride=stride)
+            d = sc.desc()
+            assert G.oracle().rto_render(G.C.byref(d), G.C.byref(p), out.ctypes.data, W, 1, None) == 0
+            return out
+
+        img = rtr.render_sharded(render_fn, W, H, rank, world)
+        if rank == 0:
+            full, _ = G.oracle_render(sc, A.make_params(W, H, spp, seed=11), threads=1)
+            q.put(bool(np.array_equal(img, full)))
+        else:
+            assert img is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_is_bit_identical_to_one_rank():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
