@@ -207,8 +207,14 @@ typedef struct rtr_render_params {
      * are then added in order (more parallelism on small images).  1 = one running sum in
      * sample order, exactly like renderer.h:72-79; 0 = let the library choose. */
     int32_t spp_chunks;
-    int32_t reserved;
+    int32_t flags; /* RTR_FLAG_* */
 } rtr_render_params;
+
+/* Visit the hittable graph in the reference's own order (bvh_node left-then-right, lists in
+ * order) instead of the compiled scene.  Always on for scenes with constant_medium, whose RNG
+ * draws depend on that order; elsewhere both give the same image and this flag is a
+ * cross-check. */
+#define RTR_FLAG_REFERENCE_ORDER 1
 
 typedef struct rtr_render_stats {
     uint64_t samples;          /* camera samples finished                               */

@@ -16,10 +16,12 @@ extern "C" {
 #endif
 
 typedef struct rtr_scene_info {
-    int32_t stack_words; /* LDS traversal-stack words per lane the scene needs */
+    int32_t stack_words; /* LDS traversal-stack words per lane the reference-order traversal needs */
     int32_t has_media;   /* constant_medium present: RNG is consumed inside traversal */
     int32_t needs_uv;    /* some texture reads (u,v) */
     int32_t graph_depth; /* longest root-to-leaf chain of hittables */
+    int32_t fast_ok;     /* a compiled scene exists (no media): the order-free traversal is the default */
+    int32_t fast_instances, fast_refs, fast_stack_words;
 } rtr_scene_info;
 
 /* Host-only: the checks rtr_upload_scene() runs before touching the GPU.  Returns RTR_OK,
@@ -31,6 +33,9 @@ int rtr_test_hits(rtr_context* ctx, rtr_hit_record* recs, int64_t n);
 int rtr_test_materials(rtr_context* ctx, rtr_mat_record* recs, int64_t n);
 int rtr_test_lights(rtr_context* ctx, rtr_light_record* recs, int64_t n);
 int rtr_test_li(rtr_context* ctx, const rtr_render_params* params, rtr_li_record* recs, int64_t n);
+
+/* Make rtr_test_hits (which takes no render params) use the reference-order traversal. */
+int rtr_test_reference_order(rtr_context* ctx, int on);
 
 #ifdef __cplusplus
 }

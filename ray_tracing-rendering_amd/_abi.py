@@ -25,6 +25,7 @@ LIGHT_QUAD = 0
 INTEGRATOR_RR = 1
 INTEGRATOR_MIS = 4
 PIPELINE_AUTO, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1, 2
+FLAG_REFERENCE_ORDER = 1
 
 NODE_DTYPE = np.dtype([("type", "<i4"), ("a", "<i4"), ("b", "<i4"), ("reserved", "<i4"), ("f", "<f8", (10,))])
 MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("tex", "<i4", (4,)), ("reserved", "<i4", (3,)), ("f", "<f8", (4,))])
@@ -81,7 +82,7 @@ class RenderParamsC(C.Structure):
                 ("x1", C.c_int32), ("y1", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("rr_start_depth", C.c_int32), ("integrator", C.c_int32), ("seed", C.c_uint32),
                 ("pipeline", C.c_int32), ("tile_first", C.c_int32), ("tile_stride", C.c_int32),
-                ("spp_chunks", C.c_int32), ("reserved", C.c_int32)]
+                ("spp_chunks", C.c_int32), ("flags", C.c_int32)]
 
 
 class RenderStatsC(C.Structure):
@@ -90,7 +91,7 @@ class RenderStatsC(C.Structure):
 
 
 def make_params(width, height, spp, *, integrator=INTEGRATOR_MIS, seed=1, max_depth=50, rr_start_depth=3,
-                region=None, pipeline=PIPELINE_AUTO, tile_first=0, tile_stride=1, spp_chunks=1):
+                region=None, pipeline=PIPELINE_AUTO, tile_first=0, tile_stride=1, spp_chunks=1, flags=0):
     """Build an ``rtr_render_params``.  Defaults follow the reference driver (main.cpp:102,
     mis_path_integrator.h:237)."""
     x0, y0, x1, y1 = region if region is not None else (0, 0, width, height)
@@ -101,4 +102,5 @@ def make_params(width, height, spp, *, integrator=INTEGRATOR_MIS, seed=1, max_de
     p.integrator, p.seed, p.pipeline = int(integrator), int(seed) & 0xFFFFFFFF, int(pipeline)
     p.tile_first, p.tile_stride = int(tile_first), int(tile_stride)
     p.spp_chunks = int(spp_chunks)
+    p.flags = int(flags)
     return p

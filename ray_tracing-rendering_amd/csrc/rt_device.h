@@ -134,6 +134,49 @@ struct DScene {
     int32_t n_nodes;
     int32_t n_lights;
     int32_t needs_uv; /* some texture reads (u,v): image textures */
+    /* compiled scene for the order-free fast path (scenes without media), see trace_fast() */
+    const struct FInst* finst;
+    const struct FXf* fxf;
+    const struct FRef* fref;
+    const int32_t* fexit;
+    const struct FBvh* fbvh;
+    int32_t n_finst;
+    int32_t fast_pad;
+};
+
+/*
+ * Compiled scene.  Where no constant_medium exists, a ray cast's result does not depend on
+ * the order objects are visited in (only exact ties in t could tell, and the reference resolves
+ * those by its arbitrary BVH order), so upload lowers the hittable graph to:
+ *   instance  = all primitives under the same chain of translate / rotate_y wrappers, with the
+ *               world-space box of the set; the ray is moved into the instance's frame once;
+ *   reference = one primitive of an instance + the wrappers (translate, rotate_y, flip_face) it
+ *               sits under, innermost first, whose hit() epilogues are replayed on the hit record;
+ *   BVH       = median-split box tree over an instance's references when there are many.
+ * Every primitive test and every epilogue uses the same arithmetic as the reference's hit()
+ * functions, so the hit record is bit-identical to the reference-order traversal.
+ */
+struct FInst {
+    double bmin[3], bmax[3]; /* world box of the instance (used when n_xf > 0) */
+    int32_t xf_first, n_xf;  /* transform ops, outermost first */
+    int32_t ref_first, n_ref;
+    int32_t bvh_root;        /* -1: scan the references linearly */
+    int32_t pad[3];
+};
+struct FXf {
+    int32_t type; /* RTR_NODE_TRANSLATE (f = offset) or RTR_NODE_ROTATE_Y (f[0] = sin, f[1] = cos) */
+    int32_t pad;
+    double f[3];
+};
+struct FRef {
+    int32_t node;       /* primitive node index */
+    int32_t exit_first; /* into fexit: wrapper node indices, innermost first */
+    int32_t n_exit;
+    int32_t pad;
+};
+struct FBvh {
+    double bmin[3], bmax[3];
+    int32_t left, right; /* right < 0: leaf holding references [left, left - right) */
 };
 
 struct Hit { /* geometry/hittable.h:10-23 */
@@ -207,6 +250,103 @@ RT_DEV void sphere_uv(V3 p, Real& u, Real& v) { /* geometry/sphere.h:24-30 */
     v = theta / RT_PI;
 }
 
+/* ---- primitive tests shared by both traversals ------------------------------------------------ */
+/* x?_rect::hit (geometry/aarect.h:79-135): t and the in-plane coordinates (a, b) */
+RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real tmax, Real& t, Real& a, Real& b) {
+    Real ok, dk, oa, da, ob, db;
+    if (type == RTR_NODE_XY_RECT) {
+        ok = o.z, dk = d.z, oa = o.x, da = d.x, ob = o.y, db = d.y;
+    } else if (type == RTR_NODE_XZ_RECT) {
+        ok = o.y, dk = d.y, oa = o.x, da = d.x, ob = o.z, db = d.z;
+    } else {
+        ok = o.x, dk = d.x, oa = o.y, da = d.y, ob = o.z, db = d.z;
+    }
+    t = (n.f[4] - ok) / dk;
+    if (t < tmin || t > tmax) return false;
+    a = oa + t * da;
+    b = ob + t * db;
+    if (a < n.f[0] || a > n.f[1] || b < n.f[2] || b > n.f[3]) return false;
+    return true;
+}
+RT_DEV void rect_fill(const rtr_node& n, int type, V3 o, V3 d, Real t, Real a, Real b, bool needs_uv, Hit& rec) {
+    if (needs_uv) {
+        rec.u = (a - n.f[0]) / (n.f[1] - n.f[0]);
+        rec.v = (b - n.f[2]) / (n.f[3] - n.f[2]);
+    }
+    rec.t = t;
+    V3 outward = mk(type == RTR_NODE_YZ_RECT ? 1.0 : 0.0, type == RTR_NODE_XZ_RECT ? 1.0 : 0.0,
+                    type == RTR_NODE_XY_RECT ? 1.0 : 0.0);
+    set_face_normal(rec, d, outward);
+    rec.mat = n.a;
+    rec.p = add(o, scl(t, d));
+}
+/* sphere::hit / moving_sphere::hit (geometry/sphere.h:33-60, moving_sphere.h:32-62) */
+RT_DEV void sphere_geom(const rtr_node& n, int type, Real time, V3& center, Real& radius) {
+    if (type == RTR_NODE_SPHERE) {
+        center = ld3(n.f);
+        radius = n.f[3];
+    } else {
+        V3 c0 = ld3(n.f), c1 = ld3(n.f + 3);
+        center = add(c0, scl((time - n.f[6]) / (n.f[7] - n.f[6]), sub(c1, c0)));
+        radius = n.f[8];
+    }
+}
+RT_DEV bool sphere_hit_t(V3 center, Real radius, V3 o, V3 d, Real tmin, Real tmax, Real& t) {
+    V3 oc = sub(o, center);
+    Real a = len2(d);
+    Real half_b = dot(oc, d);
+    Real c = len2(oc) - radius * radius;
+    Real discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return false;
+    Real sqrtd = __builtin_sqrt(discriminant);
+    t = (-half_b - sqrtd) / a;
+    if (t < tmin || t > tmax) {
+        t = (-half_b + sqrtd) / a;
+        if (t < tmin || t > tmax) return false;
+    }
+    return true;
+}
+RT_DEV void sphere_fill(const rtr_node& n, int type, V3 center, Real radius, V3 o, V3 d, Real t, bool needs_uv,
+                        Hit& rec) {
+    rec.t = t;
+    rec.p = add(o, scl(t, d));
+    V3 outward = divs(sub(rec.p, center), radius);
+    set_face_normal(rec, d, outward);
+    if (type == RTR_NODE_SPHERE && needs_uv) sphere_uv(outward, rec.u, rec.v); /* moving_sphere sets no u,v */
+    rec.mat = n.a;
+}
+/* the part of translate::hit / rotate_y::hit / flip_face::hit that runs after the child hit
+ * (geometry/hittable.h:58-61,142-155,168); `d` is the direction of the ray the wrapper passed down */
+RT_DEV void wrapper_epilogue(const rtr_node& n, V3 d, Hit& rec) {
+    const int type = n.type;
+    if (type == RTR_NODE_TRANSLATE) {
+        rec.p = add(rec.p, ld3(n.f));
+        set_face_normal(rec, d, rec.n);
+    } else if (type == RTR_NODE_ROTATE_Y) {
+        const Real s = n.f[0], c = n.f[1];
+        V3 p = rec.p, nn = rec.n;
+        p.x = c * rec.p.x + s * rec.p.z;
+        p.z = -s * rec.p.x + c * rec.p.z;
+        nn.x = c * rec.n.x + s * rec.n.z;
+        nn.z = -s * rec.n.x + c * rec.n.z;
+        rec.p = p;
+        set_face_normal(rec, d, nn);
+    } else {
+        rec.front = !rec.front;
+    }
+}
+/* the ray translate::hit / rotate_y::hit pass down (hittable.h:53,128-138) */
+RT_DEV void wrapper_enter(int type, const double* f, V3& o, V3& d) {
+    if (type == RTR_NODE_TRANSLATE) {
+        o = sub(o, ld3(f));
+    } else {
+        const Real s = f[0], c = f[1];
+        const Real ox = c * o.x - s * o.z, oz = s * o.x + c * o.z;
+        const Real dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
+        o.x = ox, o.z = oz, d.x = dx, d.z = dz;
+    }
+}
+
 /*
  * Closest hit of the hittable graph under `root`: an iterative restatement of the
  * reference's recursive virtual hit() calls that visits objects in the same order
@@ -230,30 +370,15 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
             const rtr_node& n = sc.nodes[-(e + 1)];
             const bool inside = st.get(--sp) != hits;
             const int type = n.type;
-            if (type == RTR_NODE_TRANSLATE) { /* geometry/hittable.h:58-61 */
-                if (FULL && inside) {
-                    rec.p = add(rec.p, ld3(n.f));
-                    set_face_normal(rec, d, rec.n);
-                }
+            if (FULL && inside) wrapper_epilogue(n, d, rec);
+            if (type == RTR_NODE_TRANSLATE) {
                 sp -= 6;
                 o = mk(st.getd(sp), st.getd(sp + 2), st.getd(sp + 4));
-            } else if (type == RTR_NODE_ROTATE_Y) { /* geometry/hittable.h:142-155 */
-                if (FULL && inside) {
-                    const Real s = n.f[0], c = n.f[1];
-                    V3 p = rec.p, nn = rec.n;
-                    p.x = c * rec.p.x + s * rec.p.z;
-                    p.z = -s * rec.p.x + c * rec.p.z;
-                    nn.x = c * rec.n.x + s * rec.n.z;
-                    nn.z = -s * rec.n.x + c * rec.n.z;
-                    rec.p = p;
-                    set_face_normal(rec, d, nn);
-                }
+            } else if (type == RTR_NODE_ROTATE_Y) {
                 sp -= 12;
                 o.x = st.getd(sp), o.z = st.getd(sp + 2);
                 d.x = st.getd(sp + 4), d.z = st.getd(sp + 6);
                 inv.x = st.getd(sp + 8), inv.z = st.getd(sp + 10);
-            } else { /* flip_face, geometry/hittable.h:163-170 */
-                if (FULL && inside) rec.front = !rec.front;
             }
             continue;
         }
@@ -264,74 +389,21 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
                 st.put(sp++, n.b);
                 st.put(sp++, n.a);
             }
-        } else if (type >= RTR_NODE_XY_RECT) { /* geometry/aarect.h:79-135 */
-            const Real k = n.f[4];
-            Real ok, dk, oa, da, ob, db;
-            if (type == RTR_NODE_XY_RECT) {
-                ok = o.z, dk = d.z, oa = o.x, da = d.x, ob = o.y, db = d.y;
-            } else if (type == RTR_NODE_XZ_RECT) {
-                ok = o.y, dk = d.y, oa = o.x, da = d.x, ob = o.z, db = d.z;
-            } else {
-                ok = o.x, dk = d.x, oa = o.y, da = d.y, ob = o.z, db = d.z;
-            }
-            const Real t = (k - ok) / dk;
-            if (!(t < tmin || t > tmax)) {
-                const Real a = oa + t * da;
-                const Real b = ob + t * db;
-                if (!(a < n.f[0] || a > n.f[1] || b < n.f[2] || b > n.f[3])) {
-                    tmax = t;
-                    ++hits;
-                    if (FULL) {
-                        if (sc.needs_uv) {
-                            rec.u = (a - n.f[0]) / (n.f[1] - n.f[0]);
-                            rec.v = (b - n.f[2]) / (n.f[3] - n.f[2]);
-                        }
-                        rec.t = t;
-                        V3 outward = mk(type == RTR_NODE_YZ_RECT ? 1.0 : 0.0, type == RTR_NODE_XZ_RECT ? 1.0 : 0.0,
-                                        type == RTR_NODE_XY_RECT ? 1.0 : 0.0);
-                        set_face_normal(rec, d, outward);
-                        rec.mat = n.a;
-                        rec.p = add(o, scl(t, d));
-                    }
-                }
+        } else if (type >= RTR_NODE_XY_RECT) {
+            Real t, a, b;
+            if (rect_hit_t(n, type, o, d, tmin, tmax, t, a, b)) {
+                tmax = t;
+                ++hits;
+                if (FULL) rect_fill(n, type, o, d, t, a, b, sc.needs_uv != 0, rec);
             }
         } else if (type == RTR_NODE_SPHERE || type == RTR_NODE_MOVING_SPHERE) {
-            /* geometry/sphere.h:33-60, geometry/moving_sphere.h:32-62 */
             V3 center;
-            Real radius;
-            if (type == RTR_NODE_SPHERE) {
-                center = ld3(n.f);
-                radius = n.f[3];
-            } else {
-                V3 c0 = ld3(n.f), c1 = ld3(n.f + 3);
-                center = add(c0, scl((time - n.f[6]) / (n.f[7] - n.f[6]), sub(c1, c0)));
-                radius = n.f[8];
-            }
-            V3 oc = sub(o, center);
-            Real a = len2(d);
-            Real half_b = dot(oc, d);
-            Real c = len2(oc) - radius * radius;
-            Real discriminant = half_b * half_b - a * c;
-            if (!(discriminant < 0)) {
-                Real sqrtd = __builtin_sqrt(discriminant);
-                Real root_t = (-half_b - sqrtd) / a;
-                bool ok = true;
-                if (root_t < tmin || root_t > tmax) {
-                    root_t = (-half_b + sqrtd) / a;
-                    if (root_t < tmin || root_t > tmax) ok = false;
-                }
-                if (ok) {
-                    tmax = root_t;
-                    ++hits;
-                    if (FULL) {
-                        rec.t = root_t;
-                        rec.p = add(o, scl(root_t, d));
-                        V3 outward = divs(sub(rec.p, center), radius);
-                        set_face_normal(rec, d, outward);
-                        if (type == RTR_NODE_SPHERE && sc.needs_uv) sphere_uv(outward, rec.u, rec.v);
-                        rec.mat = n.a;
-                    }
-                }
+            Real radius, t;
+            sphere_geom(n, type, time, center, radius);
+            if (sphere_hit_t(center, radius, o, d, tmin, tmax, t)) {
+                tmax = t;
+                ++hits;
+                if (FULL) sphere_fill(n, type, center, radius, o, d, t, sc.needs_uv != 0, rec);
             }
         } else if (type == RTR_NODE_LIST) {
             for (int k = n.b - 1; k >= 0; --k) st.put(sp++, sc.list_children[n.a + k]);
@@ -340,7 +412,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
             sp += 6;
             st.put(sp++, hits);
             st.put(sp++, -(e + 1));
-            o = sub(o, ld3(n.f));
+            wrapper_enter(type, n.f, o, d);
             st.put(sp++, n.a);
         } else if (type == RTR_NODE_ROTATE_Y) { /* geometry/hittable.h:127-140 */
             st.putd(sp, o.x), st.putd(sp + 2, o.z), st.putd(sp + 4, d.x), st.putd(sp + 6, d.z);
@@ -348,10 +420,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
             sp += 12;
             st.put(sp++, hits);
             st.put(sp++, -(e + 1));
-            const Real s = n.f[0], c = n.f[1];
-            const Real ox = c * o.x - s * o.z, oz = s * o.x + c * o.z;
-            const Real dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
-            o.x = ox, o.z = oz, d.x = dx, d.z = dz;
+            wrapper_enter(type, n.f, o, d);
             inv.x = 1.0 / d.x, inv.z = 1.0 / d.z;
             st.put(sp++, n.a);
         } else if (type == RTR_NODE_FLIP_FACE) {
@@ -388,6 +457,180 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
         }
     }
     return hits > 0;
+}
+
+/* ---- order-free traversal of the compiled scene ---------------------------------------------- */
+/* slab test returning the entry distance (any conservative box test is valid here: the boxes
+ * are padded at build time and only prune work) */
+RT_DEV bool box_enter(const double* bmin, const double* bmax, V3 o, V3 inv, Real tmin, Real tmax, Real& tnear) {
+    Real x0 = (bmin[0] - o.x) * inv.x, x1 = (bmax[0] - o.x) * inv.x;
+    Real y0 = (bmin[1] - o.y) * inv.y, y1 = (bmax[1] - o.y) * inv.y;
+    Real z0 = (bmin[2] - o.z) * inv.z, z1 = (bmax[2] - o.z) * inv.z;
+    Real lo = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)),
+                             __builtin_fmax(__builtin_fmin(z0, z1), tmin));
+    Real hi = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)),
+                             __builtin_fmin(__builtin_fmax(z0, z1), tmax));
+    tnear = lo;
+    return lo <= hi; /* NaNs (0 * inf) drop out of fmin/fmax, which keeps the test conservative */
+}
+
+/* one reference of an instance against the ray in the instance frame */
+RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
+    const rtr_node& n = sc.nodes[sc.fref[ref].node];
+    const int type = n.type;
+    if (type >= RTR_NODE_XY_RECT) {
+        Real a, b;
+        return rect_hit_t(n, type, o, d, tmin, tmax, t, a, b);
+    }
+    V3 center;
+    Real radius;
+    sphere_geom(n, type, time, center, radius);
+    return sphere_hit_t(center, radius, o, d, tmin, tmax, t);
+}
+
+/* Closest hit (ANY = false) or first hit found (ANY = true: shadow rays only need existence).
+ * Returns the reference and instance of the hit; `tmax` returns its t. */
+template <bool ANY>
+__device__ __forceinline__ bool trace_fast(const DScene& sc, V3 o, V3 d, Real time, Real tmin, Real& tmax,
+                                           int& hit_ref, int& hit_inst, const Stack st) {
+    const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    hit_ref = -1;
+    hit_inst = -1;
+    for (int ii = 0; ii < sc.n_finst; ++ii) {
+        const FInst& I = sc.finst[ii];
+        V3 lo = o, ld = d, linv = inv;
+        const int n_xf = I.n_xf;
+        if (n_xf) {
+            Real tn;
+            if (!box_enter(I.bmin, I.bmax, o, inv, tmin, tmax, tn)) continue;
+            bool rotated = false;
+            for (int k = 0; k < n_xf; ++k) {
+                const FXf& x = sc.fxf[I.xf_first + k];
+                wrapper_enter(x.type, x.f, lo, ld);
+                rotated |= x.type == RTR_NODE_ROTATE_Y;
+            }
+            if (rotated && I.bvh_root >= 0) linv = mk(1.0 / ld.x, 1.0 / ld.y, 1.0 / ld.z);
+        }
+        if (I.bvh_root < 0) {
+            const int r0 = I.ref_first, r1 = r0 + I.n_ref;
+            for (int r = r0; r < r1; ++r) {
+                Real t;
+                if (fast_ref_hit(sc, r, lo, ld, time, tmin, tmax, t)) {
+                    tmax = t;
+                    hit_ref = r;
+                    hit_inst = ii;
+                    if (ANY) return true;
+                }
+            }
+        } else {
+            int sp = 0;
+            st.put(sp++, I.bvh_root);
+            while (sp > 0) {
+                const FBvh& b = sc.fbvh[st.get(--sp)];
+                if (b.right < 0) {
+                    for (int r = b.left; r < b.left - b.right; ++r) {
+                        Real t;
+                        if (fast_ref_hit(sc, r, lo, ld, time, tmin, tmax, t)) {
+                            tmax = t;
+                            hit_ref = r;
+                            hit_inst = ii;
+                            if (ANY) return true;
+                        }
+                    }
+                    continue;
+                }
+                const FBvh& L = sc.fbvh[b.left];
+                const FBvh& R = sc.fbvh[b.right];
+                Real tl, tr;
+                const bool hl = box_enter(L.bmin, L.bmax, lo, linv, tmin, tmax, tl);
+                const bool hr = box_enter(R.bmin, R.bmax, lo, linv, tmin, tmax, tr);
+                if (hl && hr) { /* nearer child first */
+                    const bool left_first = tl <= tr;
+                    st.put(sp++, left_first ? b.right : b.left);
+                    st.put(sp++, left_first ? b.left : b.right);
+                } else if (hl) {
+                    st.put(sp++, b.left);
+                } else if (hr) {
+                    st.put(sp++, b.right);
+                }
+            }
+        }
+    }
+    return hit_ref >= 0;
+}
+
+/* Build the reference's hit_record for (reference, instance, t): the primitive's own hit()
+ * tail in the instance frame, then the epilogues of the wrappers above it, innermost first. */
+RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec) {
+    const FInst& I = sc.finst[inst];
+    const FRef& R = sc.fref[ref];
+    V3 lo = o, ld = d;
+    for (int k = 0; k < I.n_xf; ++k) {
+        const FXf& x = sc.fxf[I.xf_first + k];
+        wrapper_enter(x.type, x.f, lo, ld);
+    }
+    const rtr_node& n = sc.nodes[R.node];
+    const int type = n.type;
+    if (type >= RTR_NODE_XY_RECT) {
+        Real oa, da, ob, db;
+        if (type == RTR_NODE_XY_RECT) {
+            oa = lo.x, da = ld.x, ob = lo.y, db = ld.y;
+        } else if (type == RTR_NODE_XZ_RECT) {
+            oa = lo.x, da = ld.x, ob = lo.z, db = ld.z;
+        } else {
+            oa = lo.y, da = ld.y, ob = lo.z, db = ld.z;
+        }
+        rect_fill(n, type, lo, ld, t, oa + t * da, ob + t * db, sc.needs_uv != 0, rec);
+    } else {
+        V3 center;
+        Real radius;
+        sphere_geom(n, type, time, center, radius);
+        sphere_fill(n, type, center, radius, lo, ld, t, sc.needs_uv != 0, rec);
+    }
+    /* wrapper epilogues: the k-th translate/rotate_y from the inside saw the ray after the
+     * instance's first (n_xf - k) transform ops */
+    int level = I.n_xf;
+    for (int e = 0; e < R.n_exit; ++e) {
+        const rtr_node& w = sc.nodes[sc.fexit[R.exit_first + e]];
+        V3 wd = d;
+        if (w.type != RTR_NODE_FLIP_FACE) {
+            V3 wo = o;
+            for (int k = 0; k < level; ++k) {
+                const FXf& x = sc.fxf[I.xf_first + k];
+                wrapper_enter(x.type, x.f, wo, wd);
+            }
+            --level;
+        }
+        wrapper_epilogue(w, wd, rec);
+    }
+}
+
+/* ---- the two ray casts of the integrators, for either traversal ------------------------------ */
+/* TRAV: 0 = reference-order traversal, 1 = the same with constant_medium support, 2 = compiled scene */
+#define RT_TRAV_EXACT 0
+#define RT_TRAV_MEDIA 1
+#define RT_TRAV_FAST 2
+
+template <int TRAV>
+__device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real time, Hit& rec, uint32_t& rng,
+                                             const Stack st) {
+    Real tmax = RT_INF;
+    if (TRAV == RT_TRAV_FAST) {
+        int ref, inst;
+        if (!trace_fast<false>(sc, o, d, time, 0.001, tmax, ref, inst, st)) return false;
+        fast_finish(sc, o, d, time, tmax, ref, inst, rec);
+        return true;
+    }
+    return traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, time, 0.001, tmax, rec, rng, st, 0);
+}
+template <int TRAV>
+__device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real tmax, uint32_t& rng, const Stack st) {
+    if (TRAV == RT_TRAV_FAST) {
+        int ref, inst;
+        return trace_fast<true>(sc, o, d, 0.0, 0.001, tmax, ref, inst, st);
+    }
+    Hit dummy;
+    return traverse<false, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, 0.0, 0.001, tmax, dummy, rng, st, 0);
 }
 
 /* ---- materials/perlin.h:21-111 -------------------------------------------------------------- */
@@ -907,14 +1150,13 @@ RT_DEV bool shade_rr(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& 
  * closest hit, shading, inline shadow ray.  Returns false when the camera sample is
  * finished (ps.L is then its radiance).
  */
-template <int INTEG, bool MEDIA>
+template <int INTEG, int TRAV>
 __device__ __forceinline__ bool bounce(const DScene& sc, PathState& ps, uint32_t& rng, const Stack st,
                                        int max_depth, int rr_start, PathCounters& cnt) {
     Hit rec;
     rec.u = 0, rec.v = 0;
-    Real tmax = RT_INF;
     ++cnt.closest;
-    if (!traverse<true, MEDIA>(sc, sc.root, ps.ro, ps.rd, ps.tm, 0.001, tmax, rec, rng, st, 0)) {
+    if (!cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st)) {
         /* mis_path_integrator.h:48-49 / rr_path_integrator.h:31-33; no infinite light is flattened */
         ps.L = add(ps.L, mul(ps.thr, ld3(sc.background)));
         return false;
@@ -925,11 +1167,8 @@ __device__ __forceinline__ bool bounce(const DScene& sc, PathState& ps, uint32_t
         ShadowReq rq;
         shade_a_mis(sc, ps, rec, wo, rng, rq);
         if (rq.valid) {
-            Hit srec;
-            Real smax = rq.tmax;
             ++cnt.shadow;
-            if (!traverse<false, MEDIA>(sc, sc.root, rec.p, rq.wi, 0.0, 0.001, smax, srec, rng, st, 0))
-                ps.L = add(ps.L, rq.contrib);
+            if (!cast_shadow<TRAV>(sc, rec.p, rq.wi, rq.tmax, rng, st)) ps.L = add(ps.L, rq.contrib);
         } /* else the reference adds clamp_radiance(throughput * 0) = +0 (:99-103): no effect */
         go = shade_b_mis(sc, ps, rec, wo, rng, rr_start);
     } else {

@@ -45,7 +45,7 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-template <int INTEG, bool MEDIA>
+template <int INTEG, int TRAV>
 __global__ void __launch_bounds__(RTR_BLOCK) k_mega(const DScene sc, const RenderK P) {
     extern __shared__ int lds_stack[];
     const Stack st{lds_stack + threadIdx.x};
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_mega(const DScene sc, const Rende
             path_begin(ps, ro, rd, tm);
             fresh = false;
         }
-        if (!bounce<INTEG, MEDIA>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
+        if (!bounce<INTEG, TRAV>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
             acc = add(acc, ps.L); /* renderer.h:77-78 */
             ++n_samples;
             ++s;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_resolve(const ResolveK R) {
 }
 
 /* ---- device unit kernels over golden-vector records ---------------------------------------- */
-template <bool MEDIA>
+template <int TRAV>
 __global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hit_record* recs, long long n) {
     extern __shared__ int lds_stack[];
     const Stack st{lds_stack + threadIdx.x};
@@ -139,7 +139,14 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hi
     rec.mat = -1;
     rec.t = 0, rec.p = mk(0, 0, 0), rec.n = mk(0, 0, 0), rec.front = false;
     Real tmax = r.t_max;
-    const bool h = traverse<true, MEDIA>(sc, sc.root, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, rec, rng, st, 0);
+    bool h;
+    if (TRAV == RT_TRAV_FAST) {
+        int ref, inst;
+        h = trace_fast<false>(sc, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st);
+        if (h) fast_finish(sc, ld3(r.o), ld3(r.d), r.time, tmax, ref, inst, rec);
+    } else {
+        h = traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, rec, rng, st, 0);
+    }
     r.rng_out = rng;
     r.hit = h;
     r.front_face = h ? (int)rec.front : 0;
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_lights(const DScene sc, rtr_
     recs[k] = r;
 }
 
-template <int INTEG, bool MEDIA>
+template <int INTEG, int TRAV>
 __global__ void __launch_bounds__(RTR_BLOCK) k_test_li(const DScene sc, const RenderK P, rtr_li_record* recs,
                                                         long long n) {
     extern __shared__ int lds_stack[];
@@ -211,7 +218,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_li(const DScene sc, const Re
     path_begin(ps, ro, rd, tm);
     PathCounters cnt;
     cnt.closest = 0, cnt.shadow = 0;
-    while (bounce<INTEG, MEDIA>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
+    while (bounce<INTEG, TRAV>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
     }
     r.rng_exit = rng;
     r.L[0] = ps.L.x, r.L[1] = ps.L.y, r.L[2] = ps.L.z;

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const Rend
     if (slot < 2 * WF_CNT_STRIDE) S.counters[slot] = 0;
 }
 
-template <bool MEDIA>
+template <int TRAV>
 __global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const WfState S, const RenderK P,
                                                        const int parity) {
     extern __shared__ int lds_stack[];
@@ -187,9 +187,8 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const Wf
         }
         Hit rec;
         rec.u = 0, rec.v = 0;
-        Real tmax = RT_INF;
         ++n_closest;
-        if (!traverse<true, MEDIA>(sc, sc.root, ro, rd, tm, 0.001, tmax, rec, rng, st, 0)) {
+        if (!cast_closest<TRAV>(sc, ro, rd, tm, rec, rng, st)) {
             /* mis_path_integrator.h:48-49, rr_path_integrator.h:31-33 */
             V3 L = add(ldv(S.lx, S.ly, S.lz, slot), mul(ldv(S.tx, S.ty, S.tz, slot), ld3(sc.background)));
             stv(S.lx, S.ly, S.lz, slot, L);
@@ -322,7 +321,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_shade(const DScene sc, const WfS
     }
 }
 
-template <bool MEDIA>
+template <int TRAV>
 __global__ void __launch_bounds__(RTR_BLOCK) wf_connect(const DScene sc, const WfState S, const RenderK P,
                                                         const int parity) {
     extern __shared__ int lds_stack[];
@@ -334,11 +333,10 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_connect(const DScene sc, const W
         /* shadow_ray origin = rec.p (mis_path_integrator.h:210); the hit record outlives the shade stage */
         const V3 o = ldv(S.hpx, S.hpy, S.hpz, slot);
         const V3 wi = ldv(S.swx, S.swy, S.swz, slot);
-        Real tmax = S.stmax[slot];
+        const bool MEDIA = TRAV == RT_TRAV_MEDIA;
         uint32_t rng = MEDIA ? S.rng[slot] : 1u;
-        Hit dummy;
         ++n_shadow;
-        const bool hit = traverse<false, MEDIA>(sc, sc.root, o, wi, 0.0, 0.001, tmax, dummy, rng, st, 0);
+        const bool hit = cast_shadow<TRAV>(sc, o, wi, S.stmax[slot], rng, st);
         if (MEDIA) S.rng[slot] = rng;
         if (!hit) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
     }
@@ -408,7 +406,7 @@ inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
 
 /* Runs the whole render on `stream` and returns when it has finished (the iteration loop is
  * driven from the host, which polls the live-slot counter every `check` iterations). */
-inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const rtr_scene_info& info, const RenderK& Pin,
+inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const int trav, const size_t lds, const RenderK& Pin,
                             int integrator, double* d_rgb, int64_t row_stride, hipStream_t stream,
                             std::atomic<int>* cancel, int* launches, std::string& err) {
     RenderK P = Pin;
@@ -417,11 +415,11 @@ inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const rtr_sce
     WfState S{};
     int rc = wf_alloc(pool, S, (int)n_slots_ll, err);
     if (rc) return rc;
-    const size_t lds = (size_t)info.stack_words * RTR_BLOCK * sizeof(int);
-    const bool media = info.has_media != 0;
+    const bool media = trav == RT_TRAV_MEDIA;
     const bool mis = integrator == RTR_INTEGRATOR_MIS;
-    if ((rc = wf_lds_attr(wf_extend<true>, lds, err)) || (rc = wf_lds_attr(wf_extend<false>, lds, err)) ||
-        (rc = wf_lds_attr(wf_connect<true>, lds, err)) || (rc = wf_lds_attr(wf_connect<false>, lds, err)))
+    if ((rc = wf_lds_attr(wf_extend<0>, lds, err)) || (rc = wf_lds_attr(wf_extend<1>, lds, err)) ||
+        (rc = wf_lds_attr(wf_extend<2>, lds, err)) || (rc = wf_lds_attr(wf_connect<0>, lds, err)) ||
+        (rc = wf_lds_attr(wf_connect<1>, lds, err)) || (rc = wf_lds_attr(wf_connect<2>, lds, err)))
         return rc;
     const dim3 block(RTR_BLOCK);
     const int n_blocks = (S.n_slots + RTR_BLOCK - 1) / RTR_BLOCK;
@@ -441,10 +439,12 @@ inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const rtr_sce
     for (;;) {
         for (int b = 0; b < check; ++b, ++iter) {
             const int par = iter & 1;
-            if (media)
-                hipLaunchKernelGGL(wf_extend<true>, grid, block, lds, stream, sc, S, P, par);
+            if (trav == RT_TRAV_FAST)
+                hipLaunchKernelGGL(wf_extend<RT_TRAV_FAST>, grid, block, lds, stream, sc, S, P, par);
+            else if (media)
+                hipLaunchKernelGGL(wf_extend<RT_TRAV_MEDIA>, grid, block, lds, stream, sc, S, P, par);
             else
-                hipLaunchKernelGGL(wf_extend<false>, grid, block, lds, stream, sc, S, P, par);
+                hipLaunchKernelGGL(wf_extend<RT_TRAV_EXACT>, grid, block, lds, stream, sc, S, P, par);
             ++n_launch;
             if (!mis) {
                 hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_RR, 0>), grid, block, 0, stream, sc, S, P, par);
@@ -453,13 +453,16 @@ inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const rtr_sce
                 hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 0>), grid, block, 0, stream, sc, S, P, par);
                 ++n_launch;
                 if (has_lights) {
-                    hipLaunchKernelGGL(wf_connect<false>, grid, block, lds, stream, sc, S, P, par);
+                    if (trav == RT_TRAV_FAST)
+                        hipLaunchKernelGGL(wf_connect<RT_TRAV_FAST>, grid, block, lds, stream, sc, S, P, par);
+                    else
+                        hipLaunchKernelGGL(wf_connect<RT_TRAV_EXACT>, grid, block, lds, stream, sc, S, P, par);
                     ++n_launch;
                 }
             } else {
                 hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 1>), grid, block, 0, stream, sc, S, P, par);
                 if (has_lights) {
-                    hipLaunchKernelGGL(wf_connect<true>, grid, block, lds, stream, sc, S, P, par);
+                    hipLaunchKernelGGL(wf_connect<RT_TRAV_MEDIA>, grid, block, lds, stream, sc, S, P, par);
                     ++n_launch;
                 }
                 hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 2>), grid, block, 0, stream, sc, S, P, par);

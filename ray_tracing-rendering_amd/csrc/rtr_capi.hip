@@ -3,6 +3,7 @@
  * kernels of rt_kernels.h.  Host side only: scene validation and upload, launch geometry,
  * workspace, cancel, statistics.  Built by hipcc for gfx950 into librtr_hip.so.
  */
+#include "rt_compile.h"
 #include "rt_kernels.h"
 #include "rt_wavefront.h"
 #include "rtr_hip_test.h"
@@ -36,6 +37,9 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh;
+    int fast_stack_words = 1;
+    bool force_exact = false;
     /* per-render workspace */
     DevBuf b_tiles, b_partial, b_stats, b_cancel, b_test;
     WavefrontPool pool;
@@ -267,6 +271,7 @@ int params_check(rtr_context* c, const rtr_render_params* p) {
     if (p->tile_stride > 1 && (p->tile_first < 0 || p->tile_first >= p->tile_stride))
         return fail(c, RTR_ERR_INVALID, "tile_first must be in [0, tile_stride)");
     if (p->spp_chunks < 0 || p->spp_chunks > p->spp) return fail(c, RTR_ERR_INVALID, "spp_chunks must be in [0, spp]");
+    if (p->flags & ~RTR_FLAG_REFERENCE_ORDER) return fail(c, RTR_ERR_INVALID, "unknown flag bits");
     if (p->pipeline < RTR_PIPELINE_AUTO || p->pipeline > RTR_PIPELINE_WAVEFRONT)
         return fail(c, RTR_ERR_INVALID, "unknown pipeline");
     return RTR_OK;
@@ -288,7 +293,17 @@ std::vector<int> owned_tiles(const rtr_render_params& p, int& tiles_x, int& tile
     return out;
 }
 
-size_t stack_bytes(const rtr_context* c) { return (size_t)c->info.stack_words * RTR_BLOCK * sizeof(int); }
+/* which traversal a call uses: the compiled scene unless it does not exist or the caller asks
+ * for the reference's visiting order */
+int pick_trav(const rtr_context* c, int flags) {
+    if (c->info.has_media) return RT_TRAV_MEDIA;
+    if (!c->info.fast_ok || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER)) return RT_TRAV_EXACT;
+    return RT_TRAV_FAST;
+}
+size_t stack_bytes(const rtr_context* c, int trav) {
+    const int words = trav == RT_TRAV_FAST ? c->fast_stack_words : c->info.stack_words;
+    return (size_t)words * RTR_BLOCK * sizeof(int);
+}
 
 template <typename K>
 int set_lds(rtr_context* c, K kernel, size_t bytes) {
@@ -298,27 +313,29 @@ int set_lds(rtr_context* c, K kernel, size_t bytes) {
     return RTR_OK;
 }
 
-int launch_mega(rtr_context* c, const RenderK& P, int integrator) {
-    const size_t lds = stack_bytes(c);
+int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
+    const size_t lds = stack_bytes(c, trav);
     const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
-    const bool media = c->info.has_media != 0;
-#define RTR_LAUNCH(I, M)                                                      \
-    do {                                                                      \
-        int rc_ = set_lds(c, k_mega<I, M>, lds);                              \
-        if (rc_) return rc_;                                                  \
-        hipLaunchKernelGGL((k_mega<I, M>), grid, block, lds, c->stream, c->ds, P); \
+#define RTR_LAUNCH(I, T)                                                           \
+    do {                                                                           \
+        int rc_ = set_lds(c, k_mega<I, T>, lds);                                   \
+        if (rc_) return rc_;                                                       \
+        hipLaunchKernelGGL((k_mega<I, T>), grid, block, lds, c->stream, c->ds, P); \
     } while (0)
-    if (integrator == RTR_INTEGRATOR_MIS) {
-        if (media)
-            RTR_LAUNCH(RTR_INTEGRATOR_MIS, true);
-        else
-            RTR_LAUNCH(RTR_INTEGRATOR_MIS, false);
-    } else {
-        if (media)
-            RTR_LAUNCH(RTR_INTEGRATOR_RR, true);
-        else
-            RTR_LAUNCH(RTR_INTEGRATOR_RR, false);
-    }
+#define RTR_LAUNCH_T(I)                                        \
+    do {                                                       \
+        if (trav == RT_TRAV_FAST)                              \
+            RTR_LAUNCH(I, RT_TRAV_FAST);                       \
+        else if (trav == RT_TRAV_MEDIA)                        \
+            RTR_LAUNCH(I, RT_TRAV_MEDIA);                      \
+        else                                                   \
+            RTR_LAUNCH(I, RT_TRAV_EXACT);                      \
+    } while (0)
+    if (integrator == RTR_INTEGRATOR_MIS)
+        RTR_LAUNCH_T(RTR_INTEGRATOR_MIS);
+    else
+        RTR_LAUNCH_T(RTR_INTEGRATOR_RR);
+#undef RTR_LAUNCH_T
 #undef RTR_LAUNCH
     HIPCHK(c, hipGetLastError());
     return RTR_OK;
@@ -362,6 +379,13 @@ int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* 
     int rc = v.run(info);
     if (msg && msg_cap) {
         std::snprintf(msg, msg_cap, "%s", v.msg.c_str());
+    }
+    if (rc == RTR_OK && info) {
+        CompiledScene cs = compile_scene(scene, info->has_media != 0);
+        info->fast_ok = cs.ok;
+        info->fast_instances = (int32_t)cs.inst.size();
+        info->fast_refs = (int32_t)cs.ref.size();
+        info->fast_stack_words = cs.stack_words;
     }
     return rc;
 }
@@ -410,7 +434,8 @@ void rtr_destroy(rtr_context* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
-                      &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test};
+                      &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test,
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -449,7 +474,25 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     if ((rc = upload(c, c->b_images, s->images, sizeof(rtr_image) * s->n_images))) return rc;
     if ((rc = upload(c, c->b_imgbytes, s->image_bytes, s->n_image_bytes))) return rc;
     if ((rc = upload(c, c->b_lights, s->lights, sizeof(rtr_light) * s->n_lights))) return rc;
+    CompiledScene cs = compile_scene(s, info.has_media != 0);
+    info.fast_ok = cs.ok;
+    info.fast_instances = (int32_t)cs.inst.size();
+    info.fast_refs = (int32_t)cs.ref.size();
+    info.fast_stack_words = cs.stack_words;
+    if ((rc = upload(c, c->b_finst, cs.inst.data(), sizeof(FInst) * cs.inst.size()))) return rc;
+    if ((rc = upload(c, c->b_fxf, cs.xf.data(), sizeof(FXf) * cs.xf.size()))) return rc;
+    if ((rc = upload(c, c->b_fref, cs.ref.data(), sizeof(FRef) * cs.ref.size()))) return rc;
+    if ((rc = upload(c, c->b_fexit, cs.exits.data(), sizeof(int32_t) * cs.exits.size()))) return rc;
+    if ((rc = upload(c, c->b_fbvh, cs.bvh.data(), sizeof(FBvh) * cs.bvh.size()))) return rc;
+    c->fast_stack_words = cs.stack_words;
     DScene& d = c->ds;
+    d.finst = static_cast<const FInst*>(c->b_finst.p);
+    d.fxf = static_cast<const FXf*>(c->b_fxf.p);
+    d.fref = static_cast<const FRef*>(c->b_fref.p);
+    d.fexit = static_cast<const int32_t*>(c->b_fexit.p);
+    d.fbvh = static_cast<const FBvh*>(c->b_fbvh.p);
+    d.n_finst = cs.ok ? (int32_t)cs.inst.size() : 0;
+    d.fast_pad = 0;
     d.nodes = static_cast<const rtr_node*>(c->b_nodes.p);
     d.list_children = static_cast<const int32_t*>(c->b_kids.p);
     d.materials = static_cast<const rtr_material*>(c->b_mats.p);
@@ -490,6 +533,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
 
     int pipeline = p->pipeline;
     if (pipeline == RTR_PIPELINE_AUTO) pipeline = RTR_PIPELINE_MEGAKERNEL;
+    const int trav = pick_trav(c, p->flags);
     /* auto chunking: aim for >= 4096 workgroups so the 256 CUs stay fed through the tail */
     int chunks = p->spp_chunks;
     if (chunks == 0) {
@@ -515,13 +559,13 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
-        rc = wavefront_render(c->pool, c->ds, c->info, P, p->integrator, d_rgb, row_stride, c->stream,
-                              &c->cancel_requested, &launches, c->err);
+        rc = wavefront_render(c->pool, c->ds, trav, stack_bytes(c, trav), P, p->integrator, d_rgb, row_stride,
+                              c->stream, &c->cancel_requested, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
         if (rc == RTR_ERR_CANCELLED) c->cancel_requested.store(1);
         c->stats.kernel_launches = launches;
     } else {
-        if ((rc = launch_mega(c, P, p->integrator))) return rc;
+        if ((rc = launch_mega(c, P, p->integrator, trav))) return rc;
         ResolveK R{P, d_rgb, (long long)row_stride};
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), dim3(RTR_BLOCK), 0, c->stream, R);
         HIPCHK(c, hipGetLastError());
@@ -616,13 +660,17 @@ int rtr_test_hits(rtr_context* c, rtr_hit_record* recs, int64_t n) {
     DScene ds = c->ds;
     ds.needs_uv = 1; /* the vectors pin u,v although no flattened texture of these scenes reads them */
     auto* d = static_cast<rtr_hit_record*>(c->b_test.p);
-    const size_t lds = stack_bytes(c);
-    if (c->info.has_media) {
-        if ((rc = set_lds(c, k_test_hits<true>, lds))) return rc;
-        hipLaunchKernelGGL(k_test_hits<true>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
+    const int trav = pick_trav(c, 0);
+    const size_t lds = stack_bytes(c, trav);
+    if (trav == RT_TRAV_FAST) {
+        if ((rc = set_lds(c, k_test_hits<RT_TRAV_FAST>, lds))) return rc;
+        hipLaunchKernelGGL(k_test_hits<RT_TRAV_FAST>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
+    } else if (trav == RT_TRAV_MEDIA) {
+        if ((rc = set_lds(c, k_test_hits<RT_TRAV_MEDIA>, lds))) return rc;
+        hipLaunchKernelGGL(k_test_hits<RT_TRAV_MEDIA>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
     } else {
-        if ((rc = set_lds(c, k_test_hits<false>, lds))) return rc;
-        hipLaunchKernelGGL(k_test_hits<false>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
+        if ((rc = set_lds(c, k_test_hits<RT_TRAV_EXACT>, lds))) return rc;
+        hipLaunchKernelGGL(k_test_hits<RT_TRAV_EXACT>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
     }
     return test_end(c, recs, n, sizeof *recs);
 }
@@ -658,26 +706,35 @@ int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs,
     P.spp = p->spp, P.max_depth = p->max_depth, P.rr_start = p->rr_start_depth;
     P.seed = p->seed;
     auto* d = static_cast<rtr_li_record*>(c->b_test.p);
-    const size_t lds = stack_bytes(c);
-    const bool media = c->info.has_media != 0;
-#define RTR_LAUNCH(I, M)                                                                                        \
+    const int trav = pick_trav(c, p->flags);
+    const size_t lds = stack_bytes(c, trav);
+#define RTR_LAUNCH(I, T)                                                                                        \
     do {                                                                                                        \
-        if ((rc = set_lds(c, k_test_li<I, M>, lds))) return rc;                                                 \
-        hipLaunchKernelGGL((k_test_li<I, M>), test_grid(n), dim3(RTR_BLOCK), lds, c->stream, c->ds, P, d, (long long)n); \
+        if ((rc = set_lds(c, k_test_li<I, T>, lds))) return rc;                                                 \
+        hipLaunchKernelGGL((k_test_li<I, T>), test_grid(n), dim3(RTR_BLOCK), lds, c->stream, c->ds, P, d, (long long)n); \
     } while (0)
-    if (p->integrator == RTR_INTEGRATOR_MIS) {
-        if (media)
-            RTR_LAUNCH(RTR_INTEGRATOR_MIS, true);
-        else
-            RTR_LAUNCH(RTR_INTEGRATOR_MIS, false);
-    } else {
-        if (media)
-            RTR_LAUNCH(RTR_INTEGRATOR_RR, true);
-        else
-            RTR_LAUNCH(RTR_INTEGRATOR_RR, false);
-    }
+#define RTR_LAUNCH_T(I)                                        \
+    do {                                                       \
+        if (trav == RT_TRAV_FAST)                              \
+            RTR_LAUNCH(I, RT_TRAV_FAST);                       \
+        else if (trav == RT_TRAV_MEDIA)                        \
+            RTR_LAUNCH(I, RT_TRAV_MEDIA);                      \
+        else                                                   \
+            RTR_LAUNCH(I, RT_TRAV_EXACT);                      \
+    } while (0)
+    if (p->integrator == RTR_INTEGRATOR_MIS)
+        RTR_LAUNCH_T(RTR_INTEGRATOR_MIS);
+    else
+        RTR_LAUNCH_T(RTR_INTEGRATOR_RR);
+#undef RTR_LAUNCH_T
 #undef RTR_LAUNCH
     return test_end(c, recs, n, sizeof *recs);
+}
+
+int rtr_test_reference_order(rtr_context* c, int on) {
+    if (!c) return RTR_ERR_INVALID;
+    c->force_exact = on != 0;
+    return RTR_OK;
 }
 
 } /* extern "C" */

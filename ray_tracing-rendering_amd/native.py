@@ -21,12 +21,13 @@ _STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR
 EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
            "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_synchronize", "rtr_cancel",
            "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
-           "rtr_test_materials", "rtr_test_lights", "rtr_test_li")
+           "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order")
 
 
 class SceneInfoC(C.Structure):
     _fields_ = [("stack_words", C.c_int32), ("has_media", C.c_int32), ("needs_uv", C.c_int32),
-                ("graph_depth", C.c_int32)]
+                ("graph_depth", C.c_int32), ("fast_ok", C.c_int32), ("fast_instances", C.c_int32),
+                ("fast_refs", C.c_int32), ("fast_stack_words", C.c_int32)]
 
 
 class RtrError(RuntimeError):
@@ -72,6 +73,7 @@ def lib():
     for name in ("rtr_test_hits", "rtr_test_materials", "rtr_test_lights"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64]
     L.rtr_test_li.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
+    L.rtr_test_reference_order.argtypes = [vp, C.c_int]
     if L.rtr_abi_version() != A.RTR_ABI_VERSION:
         raise RtrError(A.RTR_ERR_INVALID, "librtr_hip.so ABI version mismatch")
     _LIB = L
@@ -88,7 +90,8 @@ def validate_scene(scene):
     if rc != 0:
         raise RtrError(rc, msg.value.decode())
     return {"stack_words": info.stack_words, "has_media": bool(info.has_media), "needs_uv": bool(info.needs_uv),
-            "graph_depth": info.graph_depth}
+            "graph_depth": info.graph_depth, "fast_ok": bool(info.fast_ok), "fast_instances": info.fast_instances,
+            "fast_refs": info.fast_refs, "fast_stack_words": info.fast_stack_words}
 
 
 class Context:
@@ -160,6 +163,10 @@ class Context:
         self._chk(self._L.rtr_get_stats(self._h, C.byref(s)))
         return {"samples": s.samples, "closest_segments": s.closest_segments, "shadow_segments": s.shadow_segments,
                 "device_ms": s.device_ms, "kernel_launches": s.kernel_launches, "pipeline": s.pipeline}
+
+    def reference_order(self, on):
+        """Force the reference-order traversal for rtr_test_hits (renders use params.flags)."""
+        self._chk(self._L.rtr_test_reference_order(self._h, 1 if on else 0))
 
     # device unit kernels over golden-vector records (include/rtr_hip_test.h)
     def test_records(self, kind, recs, params=None):

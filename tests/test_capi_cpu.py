@@ -36,6 +36,7 @@ def test_sample_seed_matches_oracle():
 def test_struct_sizes_match_headers():
     assert C.sizeof(A.SceneDescC) == 4 * 10 + 8 + 8 * 8 + 192 + 24
     assert C.sizeof(A.RenderParamsC) == 16 * 4
+    assert C.sizeof(rtr.native.SceneInfoC) == 8 * 4
     assert C.sizeof(A.CameraC) == 192
 
 
@@ -44,6 +45,12 @@ def test_struct_sizes_match_headers():
 def test_validate_golden_scenes(sid, words, media):
     info = rtr.native.validate_scene(G.scene(sid))
     assert info["stack_words"] == words and info["has_media"] == media and not info["needs_uv"]
+    # compiled scene (order-free traversal) exists exactly where no medium does
+    assert info["fast_ok"] == (not media)
+    if sid in (7, 21):  # world rects + two translate(rotate_y(box)) instances of 6 rects
+        assert (info["fast_instances"], info["fast_refs"], info["fast_stack_words"]) == (3, 18, 1)
+    if sid == 23:
+        assert (info["fast_instances"], info["fast_refs"]) == (1, 6)
 
 
 def _mutated(sid, fn):

@@ -200,6 +200,46 @@ def test_properties_at_full_size(ctx, pipeline):
     assert abs(other.mean() - full.mean()) <= 0.05 * full.mean()
 
 
+@pytest.mark.parametrize("sid", [7, 21, 23])
+def test_compiled_scene_equals_reference_order(ctx, sid):
+    """Scenes without media: the order-free compiled-scene traversal (default) and the
+    reference-order traversal (RTR_FLAG_REFERENCE_ORDER) must agree bit for bit."""
+    sc = _upload(ctx, sid)
+    info = rtr_info(sc)
+    assert info["fast_ok"] and not info["has_media"]
+    gold = G.records("hits_scene%02d.bin" % (21 if sid == 7 else sid), A.HIT_DTYPE)
+    ctx.reference_order(False)
+    fast = ctx.test_records("hits", gold)
+    ctx.reference_order(True)
+    exact = ctx.test_records("hits", gold)
+    ctx.reference_order(False)
+    assert np.array_equal(fast["hit"], exact["hit"])
+    h = exact["hit"] == 1
+    for f in ("front_face", "material"):
+        assert np.array_equal(fast[f][h], exact[f][h]), f
+    for f in ("t", "p", "n", "u", "v"):
+        assert np.array_equal(_bits(fast[f][h]), _bits(exact[f][h])), f
+    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
+        integ = 1 if sid == 7 else 4
+        a = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe))
+        sa = ctx.stats()
+        b = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe,
+                                     flags=A.FLAG_REFERENCE_ORDER))
+        sb = ctx.stats()
+        assert np.array_equal(_bits(a), _bits(b))
+        assert sa["closest_segments"] == sb["closest_segments"] and sa["shadow_segments"] == sb["shadow_segments"]
+
+
+def rtr_info(sc):
+    return G.rtr.native.validate_scene(sc)
+
+
+def test_media_scenes_keep_reference_order(ctx):
+    sc = _upload(ctx, 22)
+    info = rtr_info(sc)
+    assert info["has_media"] and not info["fast_ok"]
+
+
 def test_error_behaviour(ctx, rtr):
     sc = _upload(ctx, 21)
     with pytest.raises(rtr.RtrError) as e:
