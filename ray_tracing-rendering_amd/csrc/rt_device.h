@@ -561,6 +561,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, V3 o, V3 d, Real ti
 
 /* Build the reference's hit_record for (reference, instance, t): the primitive's own hit()
  * tail in the instance frame, then the epilogues of the wrappers above it, innermost first. */
+template <bool UV>
 RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec) {
     const FInst& I = sc.finst[inst];
     const FRef& R = sc.fref[ref];
@@ -580,12 +581,12 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
         } else {
             oa = lo.y, da = ld.y, ob = lo.z, db = ld.z;
         }
-        rect_fill(n, type, lo, ld, t, oa + t * da, ob + t * db, sc.needs_uv != 0, rec);
+        rect_fill(n, type, lo, ld, t, oa + t * da, ob + t * db, UV, rec);
     } else {
         V3 center;
         Real radius;
         sphere_geom(n, type, time, center, radius);
-        sphere_fill(n, type, center, radius, lo, ld, t, sc.needs_uv != 0, rec);
+        sphere_fill(n, type, center, radius, lo, ld, t, UV, rec);
     }
     /* wrapper epilogues: the k-th translate/rotate_y from the inside saw the ray after the
      * instance's first (n_xf - k) transform ops */
@@ -618,7 +619,7 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
     if (TRAV == RT_TRAV_FAST) {
         int ref, inst;
         if (!trace_fast<false>(sc, o, d, time, 0.001, tmax, ref, inst, st)) return false;
-        fast_finish(sc, o, d, time, tmax, ref, inst, rec);
+        fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec); /* scenes whose textures read (u,v) use the reference-order traversal */
         return true;
     }
     return traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, time, 0.001, tmax, rec, rng, st, 0);
@@ -669,7 +670,8 @@ RT_DEV Real perlin_turb(const rtr_perlin& pn, V3 p) { /* perlin.h:41-54 */
 }
 
 /* ---- materials/texture.h:11-162 ----------------------------------------------------------------- */
-__device__ inline V3 tex_value(const DScene& sc, int ix, Real u, Real v, V3 p) {
+/* checker / noise / image textures */
+__device__ inline V3 tex_value_slow(const DScene& sc, int ix, Real u, Real v, V3 p) {
     /* checker textures nest (texture.h:60-66); unrolled to a bounded loop instead of recursion */
     for (int guard = 0; guard < 8; ++guard) {
         const rtr_texture& t = sc.textures[ix];
@@ -698,6 +700,19 @@ __device__ inline V3 tex_value(const DScene& sc, int ix, Real u, Real v, V3 p) {
         return mk(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
     }
     return mk(0, 0, 0);
+}
+/* Material-set specialisation.  Upload knows which material and texture classes a scene uses;
+ * kernels are instantiated for the common diffuse-only set (lambertian + diffuse_light with
+ * solid_color textures: the Cornell boxes) without the code of the other classes, which keeps
+ * Cook-Torrance / pow() / perlin out of their register budget.  RT_MS_FULL handles everything. */
+#define RT_MS_LEAN 0
+#define RT_MS_FULL 1
+
+template <int MS = RT_MS_FULL>
+RT_DEV V3 tex_value(const DScene& sc, int ix, Real u, Real v, V3 p) {
+    const rtr_texture& t = sc.textures[ix];
+    if (MS == RT_MS_LEAN || t.type == RTR_TEX_SOLID) return ld3(t.f); /* texture.h:46-48 */
+    return tex_value_slow(sc, ix, u, v, p);
 }
 RT_DEV Real tex_scalar(const DScene& sc, int ix, Real u, Real v, V3 p) { return tex_value(sc, ix, u, v, p).x; }
 RT_DEV V3 tex_normal(const DScene& sc, int ix, Real u, Real v, V3 p) { /* texture.h:19-22 */
@@ -811,58 +826,24 @@ RT_DEV Real reflectance(Real cosine, Real ref_idx) { /* material.h:199-203 */
 }
 
 /* material::emitted(rec, wo): material.h:32-34, :222-227 (front face only) */
+template <int MS = RT_MS_FULL>
 RT_DEV V3 mat_emitted(const DScene& sc, const Hit& rec) {
     const rtr_material& m = sc.materials[rec.mat];
-    if (m.type == RTR_MAT_DIFFUSE_LIGHT && rec.front) return tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    if (m.type == RTR_MAT_DIFFUSE_LIGHT && rec.front) return tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
     return mk(0, 0, 0);
 }
 /* material::emitted(u, v, p): material.h:27-29, :218-220 (two-sided) */
+template <int MS = RT_MS_FULL>
 RT_DEV V3 mat_emitted_legacy(const DScene& sc, const Hit& rec) {
     const rtr_material& m = sc.materials[rec.mat];
-    if (m.type == RTR_MAT_DIFFUSE_LIGHT) return tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    if (m.type == RTR_MAT_DIFFUSE_LIGHT) return tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
     return mk(0, 0, 0);
 }
 
-__device__ inline bool mat_sample(const DScene& sc, const Hit& rec, V3 wo, BSDFSample& s, uint32_t& rng) {
-    const rtr_material& m = sc.materials[rec.mat];
-    const int type = m.type;
-    if (type == RTR_MAT_LAMBERTIAN) { /* material.h:79-90 */
-        V3 scatter_direction = add(rec.n, random_unit_vector(rng));
-        if (near_zero(scatter_direction)) scatter_direction = rec.n;
-        s.wi = unit(scatter_direction);
-        s.pdf = dot(rec.n, s.wi) / RT_PI;
-        s.f = divs(tex_value(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
-        s.is_specular = false;
-        return true;
-    }
-    if (type == RTR_MAT_METAL) { /* material.h:123-131 */
-        V3 reflected = reflect(unit(neg(wo)), rec.n);
-        s.wi = unit(add(reflected, scl(m.f[3], random_in_unit_sphere(rng))));
-        s.f = ld3(m.f);
-        s.pdf = 1.0;
-        s.is_specular = true;
-        return dot(s.wi, rec.n) > 0;
-    }
-    if (type == RTR_MAT_DIELECTRIC) { /* material.h:152-174 */
-        s.f = mk(1.0, 1.0, 1.0);
-        s.is_specular = true;
-        s.pdf = 1.0;
-        Real ir = m.f[0];
-        Real refraction_ratio = rec.front ? (1.0 / ir) : ir;
-        V3 unit_direction = neg(wo);
-        Real cos_theta = __builtin_fmin(dot(neg(unit_direction), rec.n), 1.0);
-        Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
-        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
-        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_next(rng)) {
-            s.wi = reflect(unit_direction, rec.n);
-            s.is_transmission = false;
-        } else {
-            s.wi = refract(unit_direction, rec.n, refraction_ratio);
-            s.is_transmission = true;
-        }
-        return true;
-    }
-    if (type == RTR_MAT_PBR) { /* material.h:245-303 */
+/* PBRMaterial::sample (material.h:245-303), out of line like pbr_eval / pbr_pdf */
+__device__ inline bool pbr_sample(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, BSDFSample& s,
+                                        uint32_t& rng) {
+    {
         V3 N = pbr_normal(sc, m, rec);
         Real rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
         rough = clampd(rough, 0.01, 1.0);
@@ -891,38 +872,86 @@ __device__ inline bool mat_sample(const DScene& sc, const Hit& rec, V3 wo, BSDFS
         if (s.pdf < 1e-6) return false;
         return true;
     }
+}
+
+template <int MS = RT_MS_FULL>
+__device__ __forceinline__ bool mat_sample(const DScene& sc, const Hit& rec, V3 wo, BSDFSample& s, uint32_t& rng) {
+    const rtr_material& m = sc.materials[rec.mat];
+    const int type = m.type;
+    if (type == RTR_MAT_LAMBERTIAN) { /* material.h:79-90 */
+        V3 scatter_direction = add(rec.n, random_unit_vector(rng));
+        if (near_zero(scatter_direction)) scatter_direction = rec.n;
+        s.wi = unit(scatter_direction);
+        s.pdf = dot(rec.n, s.wi) / RT_PI;
+        s.f = divs(tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
+        s.is_specular = false;
+        return true;
+    }
+    if (MS == RT_MS_LEAN) return false; /* diffuse_light::sample (material.h:213-216) */
+    if (type == RTR_MAT_METAL) { /* material.h:123-131 */
+        V3 reflected = reflect(unit(neg(wo)), rec.n);
+        s.wi = unit(add(reflected, scl(m.f[3], random_in_unit_sphere(rng))));
+        s.f = ld3(m.f);
+        s.pdf = 1.0;
+        s.is_specular = true;
+        return dot(s.wi, rec.n) > 0;
+    }
+    if (type == RTR_MAT_DIELECTRIC) { /* material.h:152-174 */
+        s.f = mk(1.0, 1.0, 1.0);
+        s.is_specular = true;
+        s.pdf = 1.0;
+        Real ir = m.f[0];
+        Real refraction_ratio = rec.front ? (1.0 / ir) : ir;
+        V3 unit_direction = neg(wo);
+        Real cos_theta = __builtin_fmin(dot(neg(unit_direction), rec.n), 1.0);
+        Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_next(rng)) {
+            s.wi = reflect(unit_direction, rec.n);
+            s.is_transmission = false;
+        } else {
+            s.wi = refract(unit_direction, rec.n, refraction_ratio);
+            s.is_transmission = true;
+        }
+        return true;
+    }
+    if (type == RTR_MAT_PBR) return pbr_sample(sc, m, rec, wo, s, rng);
     return false; /* diffuse_light (material.h:213-216), isotropic (base class, :42-45) */
 }
 
 /* material::eval: base 0 (material.h:48-51), lambertian without hemisphere test (:98-101), PBR (:342) */
+template <int MS = RT_MS_FULL>
 RT_DEV V3 mat_eval(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
     const rtr_material& m = sc.materials[rec.mat];
-    if (m.type == RTR_MAT_LAMBERTIAN) return divs(tex_value(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
-    if (m.type == RTR_MAT_PBR) return pbr_eval(sc, m, rec, wo, wi);
+    if (m.type == RTR_MAT_LAMBERTIAN) return divs(tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
+    if (MS != RT_MS_LEAN && m.type == RTR_MAT_PBR) return pbr_eval(sc, m, rec, wo, wi);
     return mk(0, 0, 0);
 }
 /* material::pdf: base 0 (material.h:54-57), lambertian (:92-96), PBR (:305) */
+template <int MS = RT_MS_FULL>
 RT_DEV Real mat_pdf(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
     const rtr_material& m = sc.materials[rec.mat];
     if (m.type == RTR_MAT_LAMBERTIAN) {
         Real cosine = dot(rec.n, unit(wi));
         return cosine < 0 ? 0 : cosine / RT_PI;
     }
-    if (m.type == RTR_MAT_PBR) return pbr_pdf(sc, m, rec, wo, wi);
+    if (MS != RT_MS_LEAN && m.type == RTR_MAT_PBR) return pbr_pdf(sc, m, rec, wo, wi);
     return 0.0;
 }
 /* legacy material::scatter(r_in, rec, attenuation, scattered): new ray = (rec.p, dir, r_in.time) */
-__device__ inline bool mat_scatter(const DScene& sc, V3 rd, const Hit& rec, V3& attenuation, V3& out_dir,
-                                   uint32_t& rng) {
+template <int MS = RT_MS_FULL>
+__device__ __forceinline__ bool mat_scatter(const DScene& sc, V3 rd, const Hit& rec, V3& attenuation, V3& out_dir,
+                                            uint32_t& rng) {
     const rtr_material& m = sc.materials[rec.mat];
     const int type = m.type;
     if (type == RTR_MAT_LAMBERTIAN) { /* material.h:103-112 */
         V3 scatter_direction = add(rec.n, random_unit_vector(rng));
         if (near_zero(scatter_direction)) scatter_direction = rec.n;
         out_dir = scatter_direction;
-        attenuation = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+        attenuation = tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
         return true;
     }
+    if (MS == RT_MS_LEAN) return false; /* diffuse_light::scatter (material.h:229-232) */
     if (type == RTR_MAT_METAL) { /* material.h:133-140 */
         V3 reflected = reflect(unit(rd), rec.n);
         out_dir = add(reflected, scl(m.f[3], random_in_unit_sphere(rng)));
@@ -1060,9 +1089,10 @@ struct ShadowReq {
  * shadow test (the reference evaluates them after it; they draw no random numbers), so the
  * connection can be resolved later by a separate shadow-ray stage.
  */
+template <int MS = RT_MS_FULL>
 RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, ShadowReq& rq) {
     const bool have_lights = sc.n_lights > 0;
-    V3 emitted = mat_emitted(sc, rec);
+    V3 emitted = mat_emitted<MS>(sc, rec);
     if (len2(emitted) > 0) { /* :72-94 */
         V3 L_emit;
         if (ps.depth == 0 || ps.specular_bounce) {
@@ -1085,9 +1115,9 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
         const Real ux = rng_next(rng);
         LightSample ls = light_sample(light, rec.p, ux, uy);
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
-            V3 f = mat_eval(sc, rec, wo, ls.wi);
+            V3 f = mat_eval<MS>(sc, rec, wo, ls.wi);
             Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));
-            Real bsdf_pdf = mat_pdf(sc, rec, wo, ls.wi);
+            Real bsdf_pdf = mat_pdf<MS>(sc, rec, wo, ls.wi);
             Real lpdf = ls.pdf * light_select_pdf;
             Real mis_weight = power_heuristic(lpdf, bsdf_pdf);
             V3 L_direct = divs(scl(mis_weight, scl(cos_theta, mul(f, ls.Li))), lpdf);
@@ -1101,11 +1131,12 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
 
 /* second half (mis_path_integrator.h:105-146): BSDF sampling with the legacy scatter()
  * fallback, throughput update, Russian roulette.  Returns false when the path ends. */
+template <int MS = RT_MS_FULL>
 RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, int rr_start) {
     BSDFSample bs;
-    if (!mat_sample(sc, rec, wo, bs, rng)) { /* :106-118 */
+    if (!mat_sample<MS>(sc, rec, wo, bs, rng)) { /* :106-118 */
         V3 attenuation, ndir;
-        if (!mat_scatter(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+        if (!mat_scatter<MS>(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
         ps.thr = mul(ps.thr, attenuation);
         ps.ro = rec.p, ps.rd = ndir;
         ps.specular_bounce = false;
@@ -1131,10 +1162,11 @@ RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
 
 /* RRPathInterator::Li after a hit (rr_path_integrator.h:36-55): two-sided legacy emission,
  * legacy scatter(), roulette clamp [0.005, 0.95] tested before the ray moves on. */
+template <int MS = RT_MS_FULL>
 RT_DEV bool shade_rr(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& rng, int rr_start) {
-    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy(sc, rec)));
+    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy<MS>(sc, rec)));
     V3 attenuation, ndir;
-    if (!mat_scatter(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+    if (!mat_scatter<MS>(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
     ps.thr = mul(ps.thr, attenuation);
     if (ps.depth >= rr_start) {
         Real p_survive = clampd(max3(ps.thr), 0.005, 0.95);

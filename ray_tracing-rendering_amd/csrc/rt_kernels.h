@@ -45,10 +45,33 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-template <int INTEG, int TRAV>
-__global__ void __launch_bounds__(RTR_BLOCK) k_mega(const DScene sc, const RenderK P) {
+#ifndef RTR_MEGA_WAVES
+#define RTR_MEGA_WAVES 4 /* min waves per SIMD the register allocator must leave room for */
+#endif
+
+/* Per-lane path state that the ray casts do not touch lives in LDS between shading steps
+ * ("parked"), so it does not occupy VGPRs across the traversal loops: throughput, radiance of
+ * the sample, pixel sum, previous BSDF pdf and the pending light contribution.  Word k of lane l
+ * is park[k * RTR_BLOCK + l] (8-byte words: conflict-free ds_read_b64 / ds_write_b64). */
+#define RT_PARK_WORDS 13
+struct Park {
+    double* base;
+    RT_DEV V3 get3(int k) const { return mk(base[k * RTR_BLOCK], base[(k + 1) * RTR_BLOCK], base[(k + 2) * RTR_BLOCK]); }
+    RT_DEV void set3(int k, V3 v) const {
+        base[k * RTR_BLOCK] = v.x, base[(k + 1) * RTR_BLOCK] = v.y, base[(k + 2) * RTR_BLOCK] = v.z;
+    }
+    RT_DEV double get(int k) const { return base[k * RTR_BLOCK]; }
+    RT_DEV void set(int k, double v) const { base[k * RTR_BLOCK] = v; }
+};
+enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_CONTRIB = 9, PK_PDF = 12 };
+
+template <int INTEG, int TRAV, int MS>
+__global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES : 2)
+    k_mega(const DScene* __restrict__ scp, const RenderK P, const int stack_words) {
     extern __shared__ int lds_stack[];
+    const DScene& sc = *scp;
     const Stack st{lds_stack + threadIdx.x};
+    const Park pk{reinterpret_cast<double*>(lds_stack + stack_words * RTR_BLOCK) + threadIdx.x};
     const int slot = blockIdx.x / P.chunks, chunk = blockIdx.x % P.chunks;
     int i, j;
     bool active;
@@ -56,7 +79,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_mega(const DScene sc, const Rende
     /* samples [s, s_end) of this pixel belong to this chunk */
     int s = (int)((long long)chunk * P.spp / P.chunks);
     const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
-    V3 acc = mk(0, 0, 0);
+    pk.set3(PK_ACC, mk(0, 0, 0));
     PathCounters cnt;
     cnt.closest = 0, cnt.shadow = 0;
     uint32_t n_samples = 0;
@@ -64,26 +87,98 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_mega(const DScene sc, const Rende
     uint32_t rng = 1;
     bool fresh = true;
     bool done = !active || s >= s_end;
-    while (!done) {
-        if (fresh) { /* renderer.h:73-75 under the per-sample seed */
-            if (__hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
-            const Real u = (i + rng_next(rng)) / (P.W - 1);
-            const Real v = (j + rng_next(rng)) / (P.H - 1);
-            V3 ro, rd;
-            Real tm;
-            camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
-            path_begin(ps, ro, rd, tm);
-            fresh = false;
+    if (TRAV == RT_TRAV_MEDIA) {
+        /* media draw random numbers inside both ray casts: keep the reference's statement order */
+        V3 acc = mk(0, 0, 0);
+        while (!done) {
+            if (fresh) { /* renderer.h:73-75 under the per-sample seed */
+                if (__hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
+                const Real u = (i + rng_next(rng)) / (P.W - 1);
+                const Real v = (j + rng_next(rng)) / (P.H - 1);
+                V3 ro, rd;
+                Real tm;
+                camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
+                path_begin(ps, ro, rd, tm);
+                fresh = false;
+            }
+            if (!bounce<INTEG, TRAV>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
+                acc = add(acc, ps.L); /* renderer.h:77-78 */
+                ++n_samples;
+                ++s;
+                fresh = true;
+                done = s >= s_end;
+            }
         }
-        if (!bounce<INTEG, TRAV>(sc, ps, rng, st, P.max_depth, P.rr_start, cnt)) {
-            acc = add(acc, ps.L); /* renderer.h:77-78 */
-            ++n_samples;
-            ++s;
-            fresh = true;
-            done = s >= s_end;
+        pk.set3(PK_ACC, acc);
+    } else {
+        /* Without media the shadow ray draws nothing, so it can be cast AFTER the BSDF sample of
+         * the same bounce (the hit record is dead by then) -- right before the next closest-hit
+         * cast from the same origin.  The sums still see their terms in the reference's order. */
+        bool pending = false, ended = false;
+        V3 swi = mk(0, 0, 0);
+        Real stmax = 0;
+        while (!done) {
+            if (fresh) {
+                if (__hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
+                const Real u = (i + rng_next(rng)) / (P.W - 1);
+                const Real v = (j + rng_next(rng)) / (P.H - 1);
+                camera_get_ray(sc.camera, u, v, rng, ps.ro, ps.rd, ps.tm);
+                ps.depth = 0, ps.specular_bounce = false;
+                pk.set3(PK_THR, mk(1.0, 1.0, 1.0));
+                pk.set3(PK_L, mk(0.0, 0.0, 0.0));
+                pk.set(PK_PDF, 0.0);
+                fresh = false;
+            }
+            if (pending) { /* connection of the previous bounce, origin = that hit point = ps.ro */
+                ++cnt.shadow;
+                if (!cast_shadow<TRAV>(sc, ps.ro, swi, stmax, rng, st)) pk.set3(PK_L, add(pk.get3(PK_L), pk.get3(PK_CONTRIB)));
+                pending = false;
+            }
+            if (!ended) {
+                Hit rec;
+                rec.u = 0, rec.v = 0;
+                ++cnt.closest;
+                if (!cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st)) {
+                    pk.set3(PK_L, add(pk.get3(PK_L), mul(pk.get3(PK_THR), ld3(sc.background))));
+                    ended = true;
+                } else {
+                    ps.thr = pk.get3(PK_THR);
+                    ps.L = pk.get3(PK_L);
+                    ps.prev_bsdf_pdf = pk.get(PK_PDF);
+                    bool go;
+                    if (INTEG == RTR_INTEGRATOR_MIS) {
+                        const V3 wo = neg(unit(ps.rd));
+                        ShadowReq rq;
+                        shade_a_mis<MS>(sc, ps, rec, wo, rng, rq);
+                        if (rq.valid) {
+                            pending = true;
+                            swi = rq.wi, stmax = rq.tmax;
+                            pk.set3(PK_CONTRIB, rq.contrib);
+                        }
+                        go = shade_b_mis<MS>(sc, ps, rec, wo, rng, P.rr_start);
+                    } else {
+                        go = shade_rr<MS>(sc, ps, rec, rng, P.rr_start);
+                    }
+                    ps.ro = rec.p; /* next ray origin and shadow ray origin */
+                    pk.set3(PK_THR, ps.thr);
+                    pk.set3(PK_L, ps.L);
+                    pk.set(PK_PDF, ps.prev_bsdf_pdf);
+                    ended = !go || ++ps.depth >= P.max_depth;
+                }
+            }
+            if (ended && !pending) {
+                pk.set3(PK_ACC, add(pk.get3(PK_ACC), pk.get3(PK_L))); /* renderer.h:77-78 */
+                ++n_samples;
+                ++s;
+                fresh = true;
+                ended = false;
+                done = s >= s_end;
+            }
         }
     }
+    const V3 acc = pk.get3(PK_ACC);
     double* out = P.partial + (size_t)blockIdx.x * 3 * RTR_BLOCK + threadIdx.x;
     out[0] = acc.x;
     out[RTR_BLOCK] = acc.y;
@@ -143,7 +238,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hi
     if (TRAV == RT_TRAV_FAST) {
         int ref, inst;
         h = trace_fast<false>(sc, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st);
-        if (h) fast_finish(sc, ld3(r.o), ld3(r.d), r.time, tmax, ref, inst, rec);
+        if (h) fast_finish<true>(sc, ld3(r.o), ld3(r.d), r.time, tmax, ref, inst, rec);
     } else {
         h = traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, rec, rng, st, 0);
     }

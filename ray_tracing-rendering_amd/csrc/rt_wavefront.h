@@ -17,13 +17,18 @@
  *   wf_shade    over the concatenated material queues: emission + MIS weight, light sample
  *               (:72-103,191-229), BSDF sample, throughput, Russian roulette (:105-146);
  *               writes the next ray and, if the light sample is usable, a shadow request.
- *   wf_connect  over the shadow queue: occlusion ray (:210-213); unoccluded -> L += contrib.
+ *   wf_connect  slots whose shade stage left a shadow request: occlusion ray (:210-213);
+ *               unoccluded -> L += contrib.
  * Scenes with participating media draw random numbers INSIDE both ray casts
  * (constant_medium.h:85), so there the shade stage is split around the connect stage
  * (wf_shade_a, wf_connect, wf_shade_b) to keep the reference's draw order.
  *
- * Queue counters are double-buffered by iteration parity: wf_extend of iteration i clears
- * the counters of parity (i+1)&1, which no kernel of iteration i touches.
+ * Material queues are built only when a scene mixes material classes (otherwise every wave is
+ * already uniform and the shade stage walks the slots directly).  Their counters are
+ * double-buffered by iteration parity: wf_extend of iteration i clears the counters of parity
+ * (i+1)&1, which no kernel of iteration i touches.  Cast counts are kept per slot and summed once
+ * per render: nothing in the iteration touches a shared address except one block-aggregated
+ * atomic per queue.
  */
 #pragma once
 
@@ -36,10 +41,12 @@
 #define WF_NTYPES RTR_MAT_TYPE_COUNT
 
 enum { WF_DONE = 0, WF_NEED_SAMPLE = 1, WF_HIT = 2, WF_CONTINUE = 3 };
-/* flags word: bits 0-1 status, bit 2 specular_bounce, bit 3 "no sample yet", bits 8.. depth */
+/* flags word: bits 0-1 status, bit 2 specular_bounce, bit 3 "no sample yet", bit 4 shadow request
+ * pending, bits 8.. depth */
 #define WF_STATUS(f) ((f) & 3)
 #define WF_SPEC 4
 #define WF_FIRST 8
+#define WF_SHADOW 16
 
 struct WfState {
     /* ray */
@@ -54,10 +61,11 @@ struct WfState {
     int32_t* hmat; /* material | front_face << 30 */
     /* shadow request */
     double *swx, *swy, *swz, *stmax, *scx, *scy, *scz;
-    /* queues */
-    int32_t* q_mat;    /* [WF_NTYPES][n_slots] */
-    int32_t* q_shadow; /* [n_slots] */
-    uint32_t* counters; /* [2][WF_NTYPES + 2]: per parity: material queue sizes, shadow queue size, pad */
+    /* per-slot cast counters (summed once at the end: no per-iteration atomics) */
+    uint32_t *n_closest, *n_shadow;
+    /* material queues (only for scenes with several material classes) */
+    int32_t* q_mat;     /* [WF_NTYPES][n_slots] */
+    uint32_t* counters; /* [2][WF_NTYPES + 2]: per parity: material queue sizes */
     uint32_t* n_live;   /* slots not yet WF_DONE */
     int n_slots;
 };
@@ -117,6 +125,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const Rend
     S.ax[slot] = 0, S.ay[slot] = 0, S.az[slot] = 0;
     S.lx[slot] = 0, S.ly[slot] = 0, S.lz[slot] = 0;
     S.samp[slot] = s0 - 1;
+    S.n_closest[slot] = 0, S.n_shadow[slot] = 0;
     S.flags[slot] = active ? (WF_NEED_SAMPLE | WF_FIRST) : WF_DONE;
     if (!active) { /* pixels outside the region still own a partial-sum cell */
         double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
@@ -127,92 +136,107 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const Rend
     if (slot < 2 * WF_CNT_STRIDE) S.counters[slot] = 0;
 }
 
-template <int TRAV>
-__global__ void __launch_bounds__(RTR_BLOCK) wf_extend(const DScene sc, const WfState S, const RenderK P,
-                                                       const int parity) {
+/* once per render: fold the per-slot counters into the render statistics */
+__global__ void __launch_bounds__(RTR_BLOCK) wf_finish(const WfState S, const RenderK P) {
+    const int slot = blockIdx.x * RTR_BLOCK + threadIdx.x;
+    unsigned long long a = 0, b = 0, c = 0;
+    if (slot < S.n_slots) {
+        int i, j, chunk;
+        bool active;
+        slot_pixel(P, slot, i, j, chunk, active);
+        const int s0 = (int)((long long)chunk * P.spp / P.chunks);
+        if (active) a = (unsigned long long)(S.samp[slot] - s0); /* samp ends at s_end: finished samples */
+        b = S.n_closest[slot], c = S.n_shadow[slot];
+    }
+    a = wave_sum(a), b = wave_sum(b), c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&P.stats[0], a);
+        if (b) atomicAdd(&P.stats[1], b);
+        if (c) atomicAdd(&P.stats[2], c);
+    }
+}
+
+template <int TRAV, bool SORT>
+__global__ void __launch_bounds__(RTR_BLOCK, 4) wf_extend(const DScene* __restrict__ scp, const WfState S,
+                                                          const RenderK P, const int parity) {
     extern __shared__ int lds_stack[];
+    const DScene& sc = *scp;
     const Stack st{lds_stack + threadIdx.x};
-    if (blockIdx.x == 0 && threadIdx.x < WF_CNT_STRIDE) S.counters[(parity ^ 1) * WF_CNT_STRIDE + threadIdx.x] = 0;
+    if (SORT && blockIdx.x == 0 && threadIdx.x < WF_CNT_STRIDE)
+        S.counters[(parity ^ 1) * WF_CNT_STRIDE + threadIdx.x] = 0;
     uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
-    unsigned n_closest = 0, n_samples = 0, n_done = 0;
+    unsigned n_done = 0;
     __shared__ uint32_t lds_cnt[2 * WF_NTYPES];
     for (int base = blockIdx.x * RTR_BLOCK; base < S.n_slots; base += gridDim.x * RTR_BLOCK) {
         const int slot = base + threadIdx.x;
         int qtype = -1;
         do {
-        if (slot >= S.n_slots) break;
-        int flags = S.flags[slot];
-        int status = WF_STATUS(flags);
-        if (status == WF_DONE) break;
-        V3 ro, rd;
-        Real tm;
-        uint32_t rng;
-        if (status == WF_NEED_SAMPLE) {
-            int i, j, chunk;
-            bool active;
-            slot_pixel(P, slot, i, j, chunk, active);
-            V3 acc = ldv(S.ax, S.ay, S.az, slot);
-            if (!(flags & WF_FIRST)) { /* renderer.h:77-78: pixel_color += Li */
-                acc = add(acc, ldv(S.lx, S.ly, S.lz, slot));
-                ++n_samples;
+            if (slot >= S.n_slots) break;
+            int flags = S.flags[slot];
+            const int status = WF_STATUS(flags);
+            if (status == WF_DONE) break;
+            V3 ro, rd;
+            Real tm;
+            uint32_t rng;
+            if (status == WF_NEED_SAMPLE) {
+                int i, j, chunk;
+                bool active;
+                slot_pixel(P, slot, i, j, chunk, active);
+                V3 acc = ldv(S.ax, S.ay, S.az, slot);
+                if (!(flags & WF_FIRST)) acc = add(acc, ldv(S.lx, S.ly, S.lz, slot)); /* renderer.h:77-78 */
+                const int s = S.samp[slot] + 1;
+                S.samp[slot] = s;
+                const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+                if (s >= s_end) {
+                    S.flags[slot] = WF_DONE;
+                    double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
+                    out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
+                    ++n_done;
+                    break;
+                }
+                stv(S.ax, S.ay, S.az, slot, acc);
+                rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
+                const Real u = (i + rng_next(rng)) / (P.W - 1);
+                const Real v = (j + rng_next(rng)) / (P.H - 1);
+                camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
+                stv(S.ox, S.oy, S.oz, slot, ro);
+                stv(S.dx, S.dy, S.dz, slot, rd);
+                S.tm[slot] = tm;
+                stv(S.tx, S.ty, S.tz, slot, mk(1.0, 1.0, 1.0));
+                stv(S.lx, S.ly, S.lz, slot, mk(0.0, 0.0, 0.0));
+                S.pdf[slot] = 0.0;
+                flags = 0; /* depth 0, not specular */
+            } else {
+                ro = ldv(S.ox, S.oy, S.oz, slot);
+                rd = ldv(S.dx, S.dy, S.dz, slot);
+                tm = S.tm[slot];
+                rng = S.rng[slot];
+                flags &= ~3;
             }
-            const int s = S.samp[slot] + 1;
-            const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
-            if (s >= s_end) {
-                S.flags[slot] = WF_DONE;
-                double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
-                out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
-                ++n_done;
+            Hit rec;
+            rec.u = 0, rec.v = 0;
+            S.n_closest[slot] += 1;
+            if (!cast_closest<TRAV>(sc, ro, rd, tm, rec, rng, st)) {
+                /* mis_path_integrator.h:48-49, rr_path_integrator.h:31-33 */
+                V3 L = add(ldv(S.lx, S.ly, S.lz, slot), mul(ldv(S.tx, S.ty, S.tz, slot), ld3(sc.background)));
+                stv(S.lx, S.ly, S.lz, slot, L);
+                S.flags[slot] = flags | WF_NEED_SAMPLE;
+                S.rng[slot] = rng;
                 break;
             }
-            stv(S.ax, S.ay, S.az, slot, acc);
-            S.samp[slot] = s;
-            rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
-            const Real u = (i + rng_next(rng)) / (P.W - 1);
-            const Real v = (j + rng_next(rng)) / (P.H - 1);
-            camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
-            stv(S.ox, S.oy, S.oz, slot, ro);
-            stv(S.dx, S.dy, S.dz, slot, rd);
-            S.tm[slot] = tm;
-            stv(S.tx, S.ty, S.tz, slot, mk(1.0, 1.0, 1.0));
-            stv(S.lx, S.ly, S.lz, slot, mk(0.0, 0.0, 0.0));
-            S.pdf[slot] = 0.0;
-            flags = 0; /* depth 0, not specular */
-        } else {
-            ro = ldv(S.ox, S.oy, S.oz, slot);
-            rd = ldv(S.dx, S.dy, S.dz, slot);
-            tm = S.tm[slot];
-            rng = S.rng[slot];
-            flags &= ~3;
-        }
-        Hit rec;
-        rec.u = 0, rec.v = 0;
-        ++n_closest;
-        if (!cast_closest<TRAV>(sc, ro, rd, tm, rec, rng, st)) {
-            /* mis_path_integrator.h:48-49, rr_path_integrator.h:31-33 */
-            V3 L = add(ldv(S.lx, S.ly, S.lz, slot), mul(ldv(S.tx, S.ty, S.tz, slot), ld3(sc.background)));
-            stv(S.lx, S.ly, S.lz, slot, L);
-            S.flags[slot] = flags | WF_NEED_SAMPLE;
+            S.ht[slot] = rec.t;
+            stv(S.hpx, S.hpy, S.hpz, slot, rec.p);
+            stv(S.hnx, S.hny, S.hnz, slot, rec.n);
+            if (sc.needs_uv) S.hu[slot] = rec.u, S.hv[slot] = rec.v;
+            S.hmat[slot] = rec.mat | (rec.front ? (1 << 30) : 0);
+            S.flags[slot] = flags | WF_HIT;
             S.rng[slot] = rng;
-            break;
-        }
-        S.ht[slot] = rec.t;
-        stv(S.hpx, S.hpy, S.hpz, slot, rec.p);
-        stv(S.hnx, S.hny, S.hnz, slot, rec.n);
-        if (sc.needs_uv) S.hu[slot] = rec.u, S.hv[slot] = rec.v;
-        S.hmat[slot] = rec.mat | (rec.front ? (1 << 30) : 0);
-        S.flags[slot] = flags | WF_HIT;
-        S.rng[slot] = rng;
-        qtype = sc.materials[rec.mat].type;
+            if (SORT) qtype = sc.materials[rec.mat].type;
         } while (false);
-        wf_block_append<WF_NTYPES>(lds_cnt, cnt, S.q_mat, (size_t)S.n_slots, qtype, slot);
+        if (SORT) wf_block_append<WF_NTYPES>(lds_cnt, cnt, S.q_mat, (size_t)S.n_slots, qtype, slot);
     }
-    const unsigned long long a = wave_sum(n_samples), b = wave_sum(n_closest), d = wave_sum(n_done);
-    if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(&P.stats[0], a);
-        if (b) atomicAdd(&P.stats[1], b);
-        if (d) atomicSub(S.n_live, (uint32_t)d);
-    }
+    const unsigned long long d = wave_sum(n_done);
+    if ((threadIdx.x & 63) == 0 && d) atomicSub(S.n_live, (uint32_t)d);
 }
 
 /* k-th entry of the concatenated material queues */
@@ -249,7 +273,7 @@ RT_DEV void wf_load_path(const WfState& S, int slot, int flags, PathState& ps) {
 }
 
 /* after shade_b / shade_rr: store the continued path or mark the sample finished */
-RT_DEV void wf_store_path(const WfState& S, int slot, const PathState& ps, bool go, int max_depth) {
+RT_DEV void wf_store_path(const WfState& S, int slot, const PathState& ps, bool go, int max_depth, int extra_flags) {
     int depth = ps.depth;
     if (go) {
         stv(S.ox, S.oy, S.oz, slot, ps.ro);
@@ -258,7 +282,8 @@ RT_DEV void wf_store_path(const WfState& S, int slot, const PathState& ps, bool 
         S.pdf[slot] = ps.prev_bsdf_pdf;
         go = ++depth < max_depth;
     }
-    S.flags[slot] = (go ? WF_CONTINUE : WF_NEED_SAMPLE) | (ps.specular_bounce ? WF_SPEC : 0) | (depth << 8);
+    S.flags[slot] =
+        (go ? WF_CONTINUE : WF_NEED_SAMPLE) | (ps.specular_bounce ? WF_SPEC : 0) | (depth << 8) | extra_flags;
 }
 
 RT_DEV void wf_store_shadow(const WfState& S, int slot, const ShadowReq& rq) {
@@ -268,80 +293,82 @@ RT_DEV void wf_store_shadow(const WfState& S, int slot, const ShadowReq& rq) {
 }
 
 /* PHASE 0: whole shading (no media).  PHASE 1: first half only (emission + light sample).
- * PHASE 2: second half only (BSDF sample + roulette), after the connect stage. */
-template <int INTEG, int PHASE>
-__global__ void __launch_bounds__(RTR_BLOCK) wf_shade(const DScene sc, const WfState S, const RenderK P,
-                                                      const int parity) {
-    uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
-    __shared__ uint32_t lds_cnt[2];
-    uint32_t total = 0;
+ * PHASE 2: second half only (BSDF sample + roulette), after the connect stage.
+ * SORT: walk the material-sorted queues; otherwise walk the slots and take those that hit. */
+template <int INTEG, int PHASE, int MS, bool SORT>
+__global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? 4 : 2) wf_shade(const DScene* __restrict__ scp,
+                                                                                const WfState S, const RenderK P,
+                                                                                const int parity) {
+    const DScene& sc = *scp;
+    const uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
+    uint32_t total = (uint32_t)S.n_slots;
+    if (SORT) {
+        total = 0;
 #pragma unroll
-    for (int t = 0; t < WF_NTYPES; ++t) total += cnt[t];
-    for (uint32_t base = blockIdx.x * RTR_BLOCK; base < total; base += gridDim.x * RTR_BLOCK) {
-        const uint32_t k = base + threadIdx.x;
-        int slot = -1;
-        int want_shadow = -1;
-        do {
-        if (k >= total) break;
-        slot = wf_sorted_slot(S, cnt, k);
+        for (int t = 0; t < WF_NTYPES; ++t) total += cnt[t];
+    }
+    for (uint32_t k = blockIdx.x * RTR_BLOCK + threadIdx.x; k < total; k += gridDim.x * RTR_BLOCK) {
+        const int slot = SORT ? wf_sorted_slot(S, cnt, k) : (int)k;
         const int flags = S.flags[slot];
+        if (!SORT && WF_STATUS(flags) != WF_HIT) continue;
         Hit rec;
         wf_load_hit(sc, S, slot, rec);
         PathState ps;
         wf_load_path(S, slot, flags, ps);
         uint32_t rng = S.rng[slot];
         bool go;
+        int extra = flags & WF_SHADOW; /* phase 2 keeps what phase 1 requested */
         if (INTEG == RTR_INTEGRATOR_MIS) {
             const V3 wo = neg(unit(ps.rd));
             if (PHASE != 2) {
                 const V3 L0 = ps.L;
                 ShadowReq rq;
-                shade_a_mis(sc, ps, rec, wo, rng, rq);
+                shade_a_mis<MS>(sc, ps, rec, wo, rng, rq);
                 if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
+                extra = 0;
                 if (rq.valid) {
                     wf_store_shadow(S, slot, rq);
-                    want_shadow = 0;
+                    extra = WF_SHADOW;
                 }
             }
             if (PHASE == 1) {
                 S.rng[slot] = rng;
-                break;
+                if (extra) S.flags[slot] = flags | WF_SHADOW;
+                continue;
             }
-            go = shade_b_mis(sc, ps, rec, wo, rng, P.rr_start);
+            go = shade_b_mis<MS>(sc, ps, rec, wo, rng, P.rr_start);
         } else {
             const V3 L0 = ps.L;
-            go = shade_rr(sc, ps, rec, rng, P.rr_start);
+            go = shade_rr<MS>(sc, ps, rec, rng, P.rr_start);
             if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
+            extra = 0;
         }
-        wf_store_path(S, slot, ps, go, P.max_depth);
+        wf_store_path(S, slot, ps, go, P.max_depth, PHASE == 2 ? 0 : extra);
         S.rng[slot] = rng;
-        } while (false);
-        if (INTEG == RTR_INTEGRATOR_MIS && PHASE != 2)
-            wf_block_append<1>(lds_cnt, cnt + WF_NTYPES, S.q_shadow, 0, want_shadow, slot);
     }
 }
 
+/* occlusion rays of the pending light connections (mis_path_integrator.h:210-213) */
 template <int TRAV>
-__global__ void __launch_bounds__(RTR_BLOCK) wf_connect(const DScene sc, const WfState S, const RenderK P,
-                                                        const int parity) {
+__global__ void __launch_bounds__(RTR_BLOCK, 4) wf_connect(const DScene* __restrict__ scp, const WfState S,
+                                                           const RenderK P) {
     extern __shared__ int lds_stack[];
+    const DScene& sc = *scp;
     const Stack st{lds_stack + threadIdx.x};
-    const uint32_t total = S.counters[parity * WF_CNT_STRIDE + WF_NTYPES];
-    unsigned n_shadow = 0;
-    for (uint32_t k = blockIdx.x * RTR_BLOCK + threadIdx.x; k < total; k += gridDim.x * RTR_BLOCK) {
-        const int slot = S.q_shadow[k];
-        /* shadow_ray origin = rec.p (mis_path_integrator.h:210); the hit record outlives the shade stage */
+    for (int slot = blockIdx.x * RTR_BLOCK + threadIdx.x; slot < S.n_slots; slot += gridDim.x * RTR_BLOCK) {
+        const int flags = S.flags[slot];
+        if (!(flags & WF_SHADOW)) continue;
+        S.flags[slot] = flags & ~WF_SHADOW;
+        /* shadow_ray origin = rec.p (:210); the hit record outlives the shade stage */
         const V3 o = ldv(S.hpx, S.hpy, S.hpz, slot);
         const V3 wi = ldv(S.swx, S.swy, S.swz, slot);
         const bool MEDIA = TRAV == RT_TRAV_MEDIA;
         uint32_t rng = MEDIA ? S.rng[slot] : 1u;
-        ++n_shadow;
+        S.n_shadow[slot] += 1;
         const bool hit = cast_shadow<TRAV>(sc, o, wi, S.stmax[slot], rng, st);
         if (MEDIA) S.rng[slot] = rng;
         if (!hit) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
     }
-    const unsigned long long c = wave_sum(n_shadow);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[2], c);
 }
 
 /* ---- host driver ------------------------------------------------------------------------------ */
@@ -355,11 +382,11 @@ inline int wf_fail(std::string& err, int code, const std::string& m) {
         if (e_ != hipSuccess) return wf_fail(err, RTR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, std::string& err) {
+inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, bool sort, std::string& err) {
     const size_t n = (size_t)n_slots;
-    const size_t n_f64 = 7 + 10 + 9 + 7; /* ray, path, hit, shadow */
-    const size_t bytes = n_f64 * n * 8 + 4 * n * 4 /* rng samp flags hmat */ + (size_t)WF_NTYPES * n * 4 + n * 4 +
-                         (2 * WF_CNT_STRIDE + 2) * 4 + 256;
+    const size_t n_f64 = 33; /* ray 7, path 10, hit 9, shadow 7 */
+    const size_t bytes = n_f64 * n * 8 + 6 * n * 4 /* rng samp flags hmat n_closest n_shadow */ +
+                         (sort ? (size_t)WF_NTYPES * n * 4 : 0) + (2 * WF_CNT_STRIDE + 2) * 4 + 256;
     if (pool.slab_bytes < bytes) {
         if (pool.slab) WF_HIP(hipFree(pool.slab));
         pool.slab = nullptr, pool.slab_bytes = 0;
@@ -388,8 +415,9 @@ inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, std::string& e
     S.samp = i32(n);
     S.flags = i32(n);
     S.hmat = i32(n);
-    S.q_mat = i32((size_t)WF_NTYPES * n);
-    S.q_shadow = i32(n);
+    S.n_closest = reinterpret_cast<uint32_t*>(i32(n));
+    S.n_shadow = reinterpret_cast<uint32_t*>(i32(n));
+    S.q_mat = sort ? i32((size_t)WF_NTYPES * n) : nullptr;
     S.counters = reinterpret_cast<uint32_t*>(i32(2 * WF_CNT_STRIDE));
     S.n_live = reinterpret_cast<uint32_t*>(i32(2));
     S.n_slots = n_slots;
@@ -406,33 +434,51 @@ inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
 
 /* Runs the whole render on `stream` and returns when it has finished (the iteration loop is
  * driven from the host, which polls the live-slot counter every `check` iterations). */
-inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const int trav, const size_t lds, const RenderK& Pin,
-                            int integrator, double* d_rgb, int64_t row_stride, hipStream_t stream,
-                            std::atomic<int>* cancel, int* launches, std::string& err) {
+inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool has_lights, const bool lean,
+                            const bool sort, const int trav, const size_t lds, const RenderK& Pin, int integrator,
+                            double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<int>* cancel,
+                            int* launches, std::string& err) {
     RenderK P = Pin;
     const long long n_slots_ll = (long long)P.n_tiles * P.chunks * RTR_BLOCK;
     if (n_slots_ll > (1ll << 30)) return wf_fail(err, RTR_ERR_UNSUPPORTED, "path pool larger than 2^30 slots");
     WfState S{};
-    int rc = wf_alloc(pool, S, (int)n_slots_ll, err);
+    int rc = wf_alloc(pool, S, (int)n_slots_ll, sort, err);
     if (rc) return rc;
     const bool media = trav == RT_TRAV_MEDIA;
     const bool mis = integrator == RTR_INTEGRATOR_MIS;
-    if ((rc = wf_lds_attr(wf_extend<0>, lds, err)) || (rc = wf_lds_attr(wf_extend<1>, lds, err)) ||
-        (rc = wf_lds_attr(wf_extend<2>, lds, err)) || (rc = wf_lds_attr(wf_connect<0>, lds, err)) ||
-        (rc = wf_lds_attr(wf_connect<1>, lds, err)) || (rc = wf_lds_attr(wf_connect<2>, lds, err)))
-        return rc;
     const dim3 block(RTR_BLOCK);
     const int n_blocks = (S.n_slots + RTR_BLOCK - 1) / RTR_BLOCK;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)cus;
     const dim3 grid((unsigned)n_blocks); /* one slot per lane; kernels keep the grid-stride form */
     int n_launch = 0;
     WF_HIP(hipMemsetAsync(S.n_live, 0, 8, stream));
-    hipLaunchKernelGGL(wf_init, dim3((unsigned)n_blocks), block, 0, stream, S, P);
+    hipLaunchKernelGGL(wf_init, grid, block, 0, stream, S, P);
     ++n_launch;
-    const bool has_lights = sc.n_lights > 0;
+
+#define WF_EXTEND(T)                                                                                     \
+    do {                                                                                                 \
+        if ((rc = wf_lds_attr(wf_extend<T, true>, lds, err)) || (rc = wf_lds_attr(wf_extend<T, false>, lds, err))) \
+            return rc;                                                                                   \
+        if (sort)                                                                                        \
+            hipLaunchKernelGGL((wf_extend<T, true>), grid, block, lds, stream, sc, S, P, par);           \
+        else                                                                                             \
+            hipLaunchKernelGGL((wf_extend<T, false>), grid, block, lds, stream, sc, S, P, par);          \
+        ++n_launch;                                                                                      \
+    } while (0)
+#define WF_SHADE(I, PH, M)                                                                               \
+    do {                                                                                                 \
+        if (sort)                                                                                        \
+            hipLaunchKernelGGL((wf_shade<I, PH, M, true>), grid, block, 0, stream, sc, S, P, par);       \
+        else                                                                                             \
+            hipLaunchKernelGGL((wf_shade<I, PH, M, false>), grid, block, 0, stream, sc, S, P, par);      \
+        ++n_launch;                                                                                      \
+    } while (0)
+#define WF_CONNECT(T)                                                                                    \
+    do {                                                                                                 \
+        if ((rc = wf_lds_attr(wf_connect<T>, lds, err))) return rc;                                      \
+        hipLaunchKernelGGL(wf_connect<T>, grid, block, lds, stream, sc, S, P);                           \
+        ++n_launch;                                                                                      \
+    } while (0)
+
     int iter = 0;
     const int check = 32;
     bool cancelled = false;
@@ -440,33 +486,31 @@ inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const int tra
         for (int b = 0; b < check; ++b, ++iter) {
             const int par = iter & 1;
             if (trav == RT_TRAV_FAST)
-                hipLaunchKernelGGL(wf_extend<RT_TRAV_FAST>, grid, block, lds, stream, sc, S, P, par);
+                WF_EXTEND(RT_TRAV_FAST);
             else if (media)
-                hipLaunchKernelGGL(wf_extend<RT_TRAV_MEDIA>, grid, block, lds, stream, sc, S, P, par);
+                WF_EXTEND(RT_TRAV_MEDIA);
             else
-                hipLaunchKernelGGL(wf_extend<RT_TRAV_EXACT>, grid, block, lds, stream, sc, S, P, par);
-            ++n_launch;
+                WF_EXTEND(RT_TRAV_EXACT);
             if (!mis) {
-                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_RR, 0>), grid, block, 0, stream, sc, S, P, par);
-                ++n_launch;
+                if (lean)
+                    WF_SHADE(RTR_INTEGRATOR_RR, 0, RT_MS_LEAN);
+                else
+                    WF_SHADE(RTR_INTEGRATOR_RR, 0, RT_MS_FULL);
             } else if (!media) {
-                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 0>), grid, block, 0, stream, sc, S, P, par);
-                ++n_launch;
+                if (lean)
+                    WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_LEAN);
+                else
+                    WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_FULL);
                 if (has_lights) {
                     if (trav == RT_TRAV_FAST)
-                        hipLaunchKernelGGL(wf_connect<RT_TRAV_FAST>, grid, block, lds, stream, sc, S, P, par);
+                        WF_CONNECT(RT_TRAV_FAST);
                     else
-                        hipLaunchKernelGGL(wf_connect<RT_TRAV_EXACT>, grid, block, lds, stream, sc, S, P, par);
-                    ++n_launch;
+                        WF_CONNECT(RT_TRAV_EXACT);
                 }
             } else {
-                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 1>), grid, block, 0, stream, sc, S, P, par);
-                if (has_lights) {
-                    hipLaunchKernelGGL(wf_connect<RT_TRAV_MEDIA>, grid, block, lds, stream, sc, S, P, par);
-                    ++n_launch;
-                }
-                hipLaunchKernelGGL((wf_shade<RTR_INTEGRATOR_MIS, 2>), grid, block, 0, stream, sc, S, P, par);
-                n_launch += 2;
+                WF_SHADE(RTR_INTEGRATOR_MIS, 1, RT_MS_FULL);
+                if (has_lights) WF_CONNECT(RT_TRAV_MEDIA);
+                WF_SHADE(RTR_INTEGRATOR_MIS, 2, RT_MS_FULL);
             }
         }
         WF_HIP(hipGetLastError());
@@ -478,6 +522,11 @@ inline int wavefront_render(WavefrontPool& pool, const DScene& sc, const int tra
             break;
         }
     }
+#undef WF_EXTEND
+#undef WF_SHADE
+#undef WF_CONNECT
+    hipLaunchKernelGGL(wf_finish, grid, block, 0, stream, S, P);
+    ++n_launch;
     if (cancelled) { /* unfinished pixels have no sum yet: leave the caller's buffer untouched */
         if (launches) *launches = n_launch;
         return RTR_ERR_CANCELLED;

@@ -37,9 +37,11 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene;
     int fast_stack_words = 1;
     bool force_exact = false;
+    bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures */
+    int n_material_types = 0;
     /* per-render workspace */
     DevBuf b_tiles, b_partial, b_stats, b_cancel, b_test;
     WavefrontPool pool;
@@ -297,7 +299,8 @@ std::vector<int> owned_tiles(const rtr_render_params& p, int& tiles_x, int& tile
  * for the reference's visiting order */
 int pick_trav(const rtr_context* c, int flags) {
     if (c->info.has_media) return RT_TRAV_MEDIA;
-    if (!c->info.fast_ok || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER)) return RT_TRAV_EXACT;
+    if (!c->info.fast_ok || c->info.needs_uv || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER))
+        return RT_TRAV_EXACT; /* the compiled path carries no (u,v) */
     return RT_TRAV_FAST;
 }
 size_t stack_bytes(const rtr_context* c, int trav) {
@@ -314,22 +317,32 @@ int set_lds(rtr_context* c, K kernel, size_t bytes) {
 }
 
 int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
-    const size_t lds = stack_bytes(c, trav);
+    const int stack_words = (int)(stack_bytes(c, trav) / (RTR_BLOCK * sizeof(int)));
+    const size_t lds = stack_bytes(c, trav) + (size_t)RT_PARK_WORDS * RTR_BLOCK * sizeof(double);
+    const DScene* dsc = static_cast<const DScene*>(c->b_dscene.p);
     const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
-#define RTR_LAUNCH(I, T)                                                           \
-    do {                                                                           \
-        int rc_ = set_lds(c, k_mega<I, T>, lds);                                   \
-        if (rc_) return rc_;                                                       \
-        hipLaunchKernelGGL((k_mega<I, T>), grid, block, lds, c->stream, c->ds, P); \
+    const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA;
+#define RTR_LAUNCH(I, T, M)                                                                        \
+    do {                                                                                           \
+        int rc_ = set_lds(c, k_mega<I, T, M>, lds);                                                \
+        if (rc_) return rc_;                                                                       \
+        hipLaunchKernelGGL((k_mega<I, T, M>), grid, block, lds, c->stream, dsc, P, stack_words);   \
     } while (0)
-#define RTR_LAUNCH_T(I)                                        \
-    do {                                                       \
-        if (trav == RT_TRAV_FAST)                              \
-            RTR_LAUNCH(I, RT_TRAV_FAST);                       \
-        else if (trav == RT_TRAV_MEDIA)                        \
-            RTR_LAUNCH(I, RT_TRAV_MEDIA);                      \
-        else                                                   \
-            RTR_LAUNCH(I, RT_TRAV_EXACT);                      \
+#define RTR_LAUNCH_T(I)                                                     \
+    do {                                                                    \
+        if (trav == RT_TRAV_FAST) {                                         \
+            if (lean)                                                       \
+                RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_LEAN);                    \
+            else                                                            \
+                RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);                    \
+        } else if (trav == RT_TRAV_MEDIA) {                                 \
+            RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);                       \
+        } else {                                                            \
+            if (lean)                                                       \
+                RTR_LAUNCH(I, RT_TRAV_EXACT, RT_MS_LEAN);                   \
+            else                                                            \
+                RTR_LAUNCH(I, RT_TRAV_EXACT, RT_MS_FULL);                   \
+        }                                                                   \
     } while (0)
     if (integrator == RTR_INTEGRATOR_MIS)
         RTR_LAUNCH_T(RTR_INTEGRATOR_MIS);
@@ -435,7 +448,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -508,6 +521,16 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.n_lights = s->n_lights;
     d.needs_uv = info.needs_uv;
     c->info = info;
+    c->lean_materials = true;
+    unsigned type_mask = 0;
+    for (int k = 0; k < s->n_materials; ++k) type_mask |= 1u << s->materials[k].type;
+    c->n_material_types = __builtin_popcount(type_mask);
+    for (int k = 0; k < s->n_materials; ++k) {
+        const rtr_material& m = s->materials[k];
+        if (m.type != RTR_MAT_LAMBERTIAN && m.type != RTR_MAT_DIFFUSE_LIGHT) c->lean_materials = false;
+        else if (s->textures[m.tex[0]].type != RTR_TEX_SOLID) c->lean_materials = false;
+    }
+    if ((rc = upload(c, c->b_dscene, &c->ds, sizeof(DScene)))) return rc;
     c->has_scene = true;
     return RTR_OK;
 }
@@ -559,8 +582,10 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
-        rc = wavefront_render(c->pool, c->ds, trav, stack_bytes(c, trav), P, p->integrator, d_rgb, row_stride,
-                              c->stream, &c->cancel_requested, &launches, c->err);
+        const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA;
+        rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean,
+                              !lean && c->n_material_types > 1, trav, stack_bytes(c, trav), P, p->integrator, d_rgb,
+                              row_stride, c->stream, &c->cancel_requested, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
         if (rc == RTR_ERR_CANCELLED) c->cancel_requested.store(1);
         c->stats.kernel_launches = launches;

@@ -38,7 +38,8 @@ class RtrError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "librtr_hip.so")
+    # RTR_HIP_LIBRARY lets a tuning run point at an alternative build of the same ABI
+    return os.environ.get("RTR_HIP_LIBRARY") or os.path.join(_HERE, "librtr_hip.so")
 
 
 def lib():
