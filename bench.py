@@ -62,7 +62,7 @@ def cpu_baseline(pkg, scene, scene_id, integ, W, H):
     """Reference CPU path on this machine's host cores, bounded sample (about 10-30 s)."""
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_time")
-    spp = 64 if cores >= 16 else 32
+    spp = 256 if cores >= 64 else (64 if cores >= 16 else 32)
     if os.path.exists(ref) and W == H:
         try:
             t0 = time.time()

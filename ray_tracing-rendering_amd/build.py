@@ -57,5 +57,21 @@ def build_host(force=False):
     return out
 
 
+def build_cli(force=False):
+    """Headless C++ driver (host/rtr_cli.cpp) linked against librtr_hip.so: the C++ face of the boundary."""
+    src = os.path.join(HOST, "rtr_cli.cpp")
+    out = os.path.join(HERE, "rtr_cli")
+    lib = os.path.join(HERE, "librtr_hip.so")
+    if not os.path.exists(src) or not os.path.exists(lib):
+        return None
+    if not force and not _newer(out, _sources(HOST, (".cpp", ".h")) + [lib]):
+        return out
+    cmd = ["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-I" + INC, "-I" + HOST, src,
+           os.path.join(HOST, "rtr_host.cpp"), "-L" + HERE, "-lrtr_hip", "-Wl,-rpath,$ORIGIN",
+           "-Wl,--allow-shlib-undefined", "-o", out]
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build_all(force=False):
-    return {"hip": build_hip(force), "host": build_host(force)}
+    return {"hip": build_hip(force), "host": build_host(force), "cli": build_cli(force)}

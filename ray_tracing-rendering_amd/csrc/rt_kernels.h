@@ -113,30 +113,26 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
         pk.set3(PK_ACC, acc);
     } else {
         /* Without media the shadow ray draws nothing, so it can be cast AFTER the BSDF sample of
-         * the same bounce (the hit record is dead by then) -- right before the next closest-hit
-         * cast from the same origin.  The sums still see their terms in the reference's order. */
-        bool pending = false, ended = false;
-        V3 swi = mk(0, 0, 0);
-        Real stmax = 0;
+         * the same bounce, when the hit record is dead.  Every live lane runs the same phases in
+         * every iteration (closest hit, shade, shadow ray, end-of-sample + regeneration), so a wave
+         * stays in lockstep although path lengths differ; the sums still see their terms in the
+         * reference's order (emission, then the light sample of the same bounce). */
+        auto begin_sample = [&]() { /* renderer.h:73-75 under the per-sample seed */
+            rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
+            const Real u = (i + rng_next(rng)) / (P.W - 1);
+            const Real v = (j + rng_next(rng)) / (P.H - 1);
+            camera_get_ray(sc.camera, u, v, rng, ps.ro, ps.rd, ps.tm);
+            ps.depth = 0, ps.specular_bounce = false;
+            pk.set3(PK_THR, mk(1.0, 1.0, 1.0));
+            pk.set3(PK_L, mk(0.0, 0.0, 0.0));
+            pk.set(PK_PDF, 0.0);
+        };
+        if (!done) begin_sample();
         while (!done) {
-            if (fresh) {
-                if (__hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
-                const Real u = (i + rng_next(rng)) / (P.W - 1);
-                const Real v = (j + rng_next(rng)) / (P.H - 1);
-                camera_get_ray(sc.camera, u, v, rng, ps.ro, ps.rd, ps.tm);
-                ps.depth = 0, ps.specular_bounce = false;
-                pk.set3(PK_THR, mk(1.0, 1.0, 1.0));
-                pk.set3(PK_L, mk(0.0, 0.0, 0.0));
-                pk.set(PK_PDF, 0.0);
-                fresh = false;
-            }
-            if (pending) { /* connection of the previous bounce, origin = that hit point = ps.ro */
-                ++cnt.shadow;
-                if (!cast_shadow<TRAV>(sc, ps.ro, swi, stmax, rng, st)) pk.set3(PK_L, add(pk.get3(PK_L), pk.get3(PK_CONTRIB)));
-                pending = false;
-            }
-            if (!ended) {
+            bool pending = false, ended = false;
+            V3 swi = mk(0, 0, 0);
+            Real stmax = 0;
+            {
                 Hit rec;
                 rec.u = 0, rec.v = 0;
                 ++cnt.closest;
@@ -168,13 +164,16 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                     ended = !go || ++ps.depth >= P.max_depth;
                 }
             }
-            if (ended && !pending) {
+            if (pending) { /* mis_path_integrator.h:210-213, origin = the hit point = ps.ro */
+                ++cnt.shadow;
+                if (!cast_shadow<TRAV>(sc, ps.ro, swi, stmax, rng, st)) pk.set3(PK_L, add(pk.get3(PK_L), pk.get3(PK_CONTRIB)));
+            }
+            if (ended) {
                 pk.set3(PK_ACC, add(pk.get3(PK_ACC), pk.get3(PK_L))); /* renderer.h:77-78 */
                 ++n_samples;
                 ++s;
-                fresh = true;
-                ended = false;
-                done = s >= s_end;
+                done = s >= s_end || __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!done) begin_sample();
             }
         }
     }

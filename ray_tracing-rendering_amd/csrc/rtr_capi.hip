@@ -37,7 +37,7 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim;
     int fast_stack_words = 1;
     bool force_exact = false;
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures */
@@ -448,7 +448,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -497,11 +497,17 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     if ((rc = upload(c, c->b_fref, cs.ref.data(), sizeof(FRef) * cs.ref.size()))) return rc;
     if ((rc = upload(c, c->b_fexit, cs.exits.data(), sizeof(int32_t) * cs.exits.size()))) return rc;
     if ((rc = upload(c, c->b_fbvh, cs.bvh.data(), sizeof(FBvh) * cs.bvh.size()))) return rc;
+    {
+        std::vector<rtr_node> prims(cs.ref.size());
+        for (size_t k = 0; k < cs.ref.size(); ++k) prims[k] = s->nodes[cs.ref[k].node];
+        if ((rc = upload(c, c->b_fprim, prims.data(), sizeof(rtr_node) * prims.size()))) return rc;
+    }
     c->fast_stack_words = cs.stack_words;
     DScene& d = c->ds;
     d.finst = static_cast<const FInst*>(c->b_finst.p);
     d.fxf = static_cast<const FXf*>(c->b_fxf.p);
     d.fref = static_cast<const FRef*>(c->b_fref.p);
+    d.fprim = static_cast<const rtr_node*>(c->b_fprim.p);
     d.fexit = static_cast<const int32_t*>(c->b_fexit.p);
     d.fbvh = static_cast<const FBvh*>(c->b_fbvh.p);
     d.n_finst = cs.ok ? (int32_t)cs.inst.size() : 0;

@@ -1,0 +1,61 @@
+/*
+ * rtr_cli.cpp -- headless driver in the shape of the reference's main.cpp:49-153 without the
+ * SDL window: scene id and integrator id as the first two arguments (main.cpp:54-59), plus the
+ * overrides the BASELINE configurations need (--width --spp --seed --out).  It is the
+ * reference-side usage of the host layer: select_scene -> camera -> Renderer::render -> file.
+ *
+ *   rtr_cli <scene 7|9|21|22|23> <integrator 1|4> [--width W] [--spp N] [--seed S] [--out img.ppm]
+ */
+#include "rtr_renderer.h"
+
+#include <cstring>
+
+int main(int argc, char** argv) {
+    int scene_id = 21, integrator_id = 4, width = 0, spp = 0;
+    unsigned seed = 1;
+    std::string out;
+    int pos = 0;
+    for (int k = 1; k < argc; ++k) {
+        if (!std::strcmp(argv[k], "--width") && k + 1 < argc) width = std::atoi(argv[++k]);
+        else if (!std::strcmp(argv[k], "--spp") && k + 1 < argc) spp = std::atoi(argv[++k]);
+        else if (!std::strcmp(argv[k], "--seed") && k + 1 < argc) seed = (unsigned)std::strtoul(argv[++k], nullptr, 0);
+        else if (!std::strcmp(argv[k], "--out") && k + 1 < argc) out = argv[++k];
+        else if (pos == 0) scene_id = std::atoi(argv[k]), ++pos;
+        else if (pos == 1) integrator_id = std::atoi(argv[k]), ++pos;
+    }
+    rtr::rng_state() = 12345u; /* scene-construction seed */
+    SceneConfig config;
+    try {
+        config = select_scene(scene_id);
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << "\n";
+        return 2;
+    }
+    if (width > 0) config.image_width = width;
+    if (spp > 0) config.samples_per_pixel = spp;
+    auto cam = make_shared<camera>(config.lookfrom, config.lookat, config.vup, config.vfov, config.aspect_ratio,
+                                   config.aperture, config.focus_dist, 0.0, 1.0); /* main.cpp:63-66 */
+    const int W = config.image_width, H = static_cast<int>(W / config.aspect_ratio);
+    RenderBuffer buffer(W, H);
+    Renderer renderer;
+    renderer.set_samples(config.samples_per_pixel);
+    if (integrator_id == 1)
+        renderer.set_integrator(make_shared<RRPathInterator>());
+    else if (integrator_id == 4)
+        renderer.set_integrator(make_shared<MISPathIntegrator>());
+    else {
+        std::cerr << "integrator " << integrator_id << " is not on the device (1 = RR, 4 = MIS)\n";
+        return 2;
+    }
+    renderer.set_max_depth(50); /* main.cpp:102 */
+    renderer.set_seed(seed);
+    renderer.render(config.world, cam, config.background, buffer, config.lights);
+    if (renderer.last_status() != RTR_OK) return 1;
+    std::cout << "Msamples/s: " << (double)W * H * config.samples_per_pixel / renderer.last_seconds() * 1e-6
+              << " (includes flatten, upload and D2H)\n";
+    if (!out.empty() && !buffer.save_to_ppm(out)) {
+        std::cerr << "Failed to save image to " << out << "\n";
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,170 @@
+/*
+ * rtr_renderer.h -- host C++ mirror of the reference's render entry:
+ *   RenderBuffer  (renderer/render_buffer.h:11-33)
+ *   Integrator + the two integrators on the device path (renderer/integrator.h:9-21,
+ *                 mis_path_integrator.h, rr_path_integrator.h) as id-carrying tags
+ *   Renderer      (renderer/renderer.h:17-142): same methods, same blocking render() signature
+ * render() flattens the object graph (rtr_scene_api.h) and drives the HIP library through the
+ * C ABI of include/rtr_hip.h; it then applies the reference's own output stage
+ * (renderer.h:126-140: scale by 1/spp happened on the device, here sqrt + clamp).
+ * Link with -lrtr_hip (ray_tracing-rendering_amd/librtr_hip.so).  Errors the reference would
+ * print to std::cerr are printed to std::cerr; render() never throws (renderer.h has no error
+ * channel), last_status()/last_error() expose what the C ABI reported.
+ */
+#ifndef RTR_RENDERER_H
+#define RTR_RENDERER_H
+
+#include "rtr_scene_api.h"
+
+#include <atomic>
+#include <chrono>
+
+class RenderBuffer {
+  public:
+    RenderBuffer(int width, int height) : m_width(width), m_height(height) {
+        m_pixels.resize(height, std::vector<color>(width));
+    }
+    void set_pixel(int x, int y, const color& c) {
+        if (x >= 0 && x < m_width && y >= 0 && y < m_height) m_pixels[y][x] = c;
+    }
+    const std::vector<std::vector<color>>& get_data() const { return m_pixels; }
+    int width() const { return m_width; }
+    int height() const { return m_height; }
+    /* binary PPM with the bytes save_to_png encodes (render_buffer.h:39-51): Y flipped, uchar(c*255) */
+    bool save_to_ppm(const std::string& filename) const {
+        FILE* f = std::fopen(filename.c_str(), "wb");
+        if (!f) return false;
+        std::fprintf(f, "P6\n%d %d\n255\n", m_width, m_height);
+        for (int j = 0; j < m_height; ++j)
+            for (int i = 0; i < m_width; ++i) {
+                const color& p = m_pixels[m_height - 1 - j][i];
+                unsigned char px[3] = {(unsigned char)(p[0] * 255), (unsigned char)(p[1] * 255),
+                                       (unsigned char)(p[2] * 255)};
+                std::fwrite(px, 1, 3, f);
+            }
+        std::fclose(f);
+        return true;
+    }
+
+  private:
+    int m_width, m_height;
+    std::vector<std::vector<color>> m_pixels;
+};
+
+class Integrator {
+  public:
+    virtual ~Integrator() = default;
+    virtual void set_max_depth(int depth) = 0;
+    virtual int rtr_integrator_id() const = 0; /* reference CLI numbering, main.cpp:52 */
+    virtual int rtr_max_depth() const = 0;
+    virtual int rtr_rr_start() const = 0;
+};
+class MISPathIntegrator : public Integrator {
+  public:
+    void set_max_depth(int depth = 50) override { m_max_depth = depth; }
+    void set_rr_start_depth(int depth) { m_rr_start_depth = depth; }
+    int rtr_integrator_id() const override { return RTR_INTEGRATOR_MIS; }
+    int rtr_max_depth() const override { return m_max_depth; }
+    int rtr_rr_start() const override { return m_rr_start_depth; }
+
+  private:
+    int m_max_depth = 50, m_rr_start_depth = 3;
+};
+class RRPathInterator : public Integrator { /* sic: the reference's spelling */
+  public:
+    void set_max_depth(int depth = 50) override { m_max_depth = depth; }
+    void set_rr_start_depth(int depth) { m_rr_start_depth = depth; }
+    int rtr_integrator_id() const override { return RTR_INTEGRATOR_RR; }
+    int rtr_max_depth() const override { return m_max_depth; }
+    int rtr_rr_start() const override { return m_rr_start_depth; }
+
+  private:
+    int m_max_depth = 50, m_rr_start_depth = 3;
+};
+
+class Renderer {
+  public:
+    struct Settings {
+        int samples_per_pixel = 10;
+    };
+    explicit Renderer(int device = 0) : m_is_rendering(false) {
+        m_status = rtr_create(device, &m_ctx);
+        if (m_status != RTR_OK) std::cerr << "rtr_create: " << rtr_last_error(nullptr) << "\n";
+    }
+    ~Renderer() { rtr_destroy(m_ctx); }
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+
+    void set_integrator(std::shared_ptr<Integrator> integrator) { m_integrator = integrator; }
+    void set_samples(int samples) { m_settings.samples_per_pixel = samples; }
+    void set_max_depth(int depth) {
+        if (m_integrator) m_integrator->set_max_depth(depth);
+    }
+    void set_seed(uint32_t seed) { m_seed = seed; } /* the reference has no seed control */
+    void cancel() {
+        m_is_rendering = false;
+        if (m_ctx) rtr_cancel(m_ctx);
+    }
+    bool is_rendering() const { return m_is_rendering; }
+    int last_status() const { return m_status; }
+    const char* last_error() const { return rtr_last_error(m_ctx); }
+    double last_seconds() const { return m_seconds; }
+
+    void render(shared_ptr<hittable> world, shared_ptr<camera> cam, const color& background,
+                RenderBuffer& target_buffer, const std::vector<shared_ptr<Light>>& lights = {}) {
+        m_is_rendering = true;
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        m_status = render_impl(*world, *cam, background, target_buffer, lights);
+        m_seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        m_is_rendering = false;
+        if (m_status == RTR_OK)
+            std::cout << "Rendering finished in " << m_seconds << " seconds." << std::endl;
+        else
+            std::cerr << "render failed (" << m_status << "): " << m_error << "\n";
+    }
+
+  private:
+    int render_impl(const hittable& world, const camera& cam, const color& background, RenderBuffer& buf,
+                    const std::vector<shared_ptr<Light>>& lights) {
+        if (!m_ctx) return m_error = rtr_last_error(nullptr), RTR_ERR_DEVICE;
+        if (!m_integrator) return m_error = "no integrator set", RTR_ERR_INVALID;
+        rtr_scene_storage st;
+        if (!rtr::flatten(world, lights, cam, background, st, m_error)) return RTR_ERR_UNSUPPORTED;
+        rtr_scene_desc d = st.desc();
+        int rc = rtr_upload_scene(m_ctx, &d);
+        if (rc) return m_error = rtr_last_error(m_ctx), rc;
+        const int W = buf.width(), H = buf.height();
+        rtr_render_params p{};
+        p.image_width = W, p.image_height = H;
+        p.x0 = 0, p.y0 = 0, p.x1 = W, p.y1 = H;
+        p.spp = m_settings.samples_per_pixel;
+        p.max_depth = m_integrator->rtr_max_depth();
+        p.rr_start_depth = m_integrator->rtr_rr_start();
+        p.integrator = m_integrator->rtr_integrator_id();
+        p.seed = m_seed;
+        p.pipeline = RTR_PIPELINE_AUTO;
+        p.tile_first = 0, p.tile_stride = 1;
+        p.spp_chunks = 0;
+        std::vector<double> lin((size_t)W * H * 3);
+        rc = rtr_render_host(m_ctx, &p, lin.data(), W);
+        if (rc) return m_error = rtr_last_error(m_ctx), rc;
+        for (int j = 0; j < H; ++j)
+            for (int i = 0; i < W; ++i) { /* write_color_to_buffer, renderer.h:126-140 */
+                const double* px = &lin[((size_t)j * W + i) * 3];
+                buf.set_pixel(i, j, color(clamp(sqrt(px[0]), 0.0, 1.0), clamp(sqrt(px[1]), 0.0, 1.0),
+                                          clamp(sqrt(px[2]), 0.0, 1.0)));
+            }
+        return RTR_OK;
+    }
+
+    Settings m_settings;
+    std::atomic<bool> m_is_rendering;
+    std::shared_ptr<Integrator> m_integrator;
+    rtr_context* m_ctx = nullptr;
+    int m_status = RTR_OK;
+    uint32_t m_seed = 1;
+    double m_seconds = 0;
+    std::string m_error;
+};
+
+#endif /* RTR_RENDERER_H */
