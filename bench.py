@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wavefront"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1 (gloo + RTR_BENCH_ONE_GPU=1 rehearses the N>1 path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -110,11 +112,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if os.environ.get("RTR_BENCH_ONE_GPU"):
+        local_rank = 0  # rehearsal: every rank drives GPU 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        gloo = dist.new_group(backend="gloo")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            gloo = dist.new_group(backend="gloo")
+        else:
+            dist.init_process_group("gloo")
+            gloo = dist.group.WORLD
 
     scene_id, integ, W, H, spp = WORKLOADS[args.workload]
     if args.spp:
@@ -153,7 +161,8 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     st = ctx.stats()  # last step of this rank
     t = torch.tensor([sec, sum(kernel_ms) / len(kernel_ms), float(st["samples"]), float(st["closest_segments"]),
-                      float(st["shadow_segments"])], dtype=torch.float64, device="cuda")
+                      float(st["shadow_segments"])], dtype=torch.float64,
+                     device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -183,6 +192,15 @@ def main():
         value = total * args.steps / sec_max * 1e-6
         alg_bytes = samples * B_SAMPLE + closest * B_CLOSEST + shadow * B_SHADOW  # whole job, one step
         achieved = alg_bytes / world / (kms_max * 1e-3) * 1e-9  # GB/s per GPU over its kernels
+        pipe_name = {1: "megakernel", 2: "wavefront"}.get(st["pipeline"], "?")
+        traffic = None  # HBM bytes of one render from separate rocprofv3 --pmc passes (profiles/r01_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            if not args.spp and world == 1:
+                traffic = tj.get(args.workload, {}).get(pipe_name)
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "Msamples/sec, Cornell Box 800x800 spp=400 MIS" if args.workload == "cornell_mis" and not args.spp
                       else "Msamples/sec, " + args.workload,
@@ -191,10 +209,10 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "scene%02d %dx%d spp=%d depth=50 integrator%d (%s)" %
                                    (scene_id, W, H, spp, integ, args.workload),
-                       "pipeline": {1: "megakernel", 2: "wavefront"}.get(st["pipeline"], "?"),
+                       "pipeline": pipe_name,
                        "parallelism": "tiles%%%d" % world, "seed": 1},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(kms_max, 3),
                          "algorithmic_bytes_per_sample": round(alg_bytes / samples, 1)},
             "segments_per_sample": {"closest": round(closest / samples, 4), "shadow": round(shadow / samples, 4)},
