@@ -128,6 +128,27 @@ RT_DEV V3 random_cosine_direction(uint32_t& s) { /* vec3.h:261-269 */
 }
 
 /* ---- device scene ------------------------------------------------------------------------ */
+/* Scene arrays are immutable during a render.  Reading them through the constant address space
+ * tells the compiler so: wave-uniform accesses (instance / reference / primitive loops of the
+ * compiled scene) become scalar loads into SGPRs instead of 64 identical vector loads. */
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <class T>
+RT_DEV const RT_CONST_AS T* as_const(const T* p) {
+    return (const RT_CONST_AS T*)(unsigned long long)p;
+}
+/* copy record `idx` of a POD array out of the constant address space (unused fields fold away) */
+template <class T>
+RT_DEV T ld_const(const T* base, int idx) {
+    static_assert(sizeof(T) % 8 == 0, "records are multiples of 8 bytes");
+    const RT_CONST_AS unsigned long long* src = as_const(reinterpret_cast<const unsigned long long*>(base + idx));
+    unsigned long long w[sizeof(T) / 8];
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 8; ++k) w[k] = src[k];
+    T v;
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
+
 struct DScene {
     const rtr_node* nodes;
     const int32_t* list_children;
@@ -271,12 +292,13 @@ RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real 
     } else {
         ok = o.x, dk = d.x, oa = o.y, da = d.y, ob = o.z, db = d.z;
     }
+    /* same tests as aarect.h:80-88 (a NaN fails none of the rejects there, nor here), evaluated
+     * without early exits: lanes of a wave diverge on them anyway */
     t = (n.f[4] - ok) / dk;
-    if (t < tmin || t > tmax) return false;
     a = oa + t * da;
     b = ob + t * db;
-    if (a < n.f[0] || a > n.f[1] || b < n.f[2] || b > n.f[3]) return false;
-    return true;
+    const bool out = (t < tmin) | (t > tmax) | (a < n.f[0]) | (a > n.f[1]) | (b < n.f[2]) | (b > n.f[3]);
+    return !out;
 }
 RT_DEV void rect_fill(const rtr_node& n, int type, V3 o, V3 d, Real t, Real a, Real b, bool needs_uv, Hit& rec) {
     if (needs_uv) {
@@ -470,6 +492,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
 }
 
 /* ---- order-free traversal of the compiled scene ---------------------------------------------- */
+#define RT_FAST_NO_BOX_MAX 4
 /* slab test returning the entry distance (any conservative box test is valid here: the boxes
  * are padded at build time and only prune work) */
 RT_DEV bool box_enter(const double* bmin, const double* bmax, V3 o, V3 inv, Real tmin, Real tmax, Real& tnear) {
@@ -486,7 +509,7 @@ RT_DEV bool box_enter(const double* bmin, const double* bmax, V3 o, V3 inv, Real
 
 /* one reference of an instance against the ray in the instance frame */
 RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
-    const rtr_node& n = sc.fprim[ref];
+    const rtr_node n = ld_const(sc.fprim, ref);
     const int type = n.type;
     if (type >= RTR_NODE_XY_RECT) {
         Real a, b;
@@ -503,24 +526,28 @@ RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real 
 template <bool ANY>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, V3 o, V3 d, Real time, Real tmin, Real& tmax,
                                            int& hit_ref, int& hit_inst, const Stack st) {
-    const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    /* with a handful of instances some lane of the wave enters every one of them, so the boxes
+     * would prune nothing at wave level: skip them (and the three divisions of 1/d) */
+    const bool use_boxes = sc.n_finst > RT_FAST_NO_BOX_MAX;
+    V3 inv = mk(0, 0, 0);
+    if (use_boxes) inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     hit_ref = -1;
     hit_inst = -1;
     for (int ii = 0; ii < sc.n_finst; ++ii) {
-        const FInst& I = sc.finst[ii];
+        const FInst I = ld_const(sc.finst, ii);
         V3 lo = o, ld = d, linv = inv;
         const int n_xf = I.n_xf;
         if (n_xf) {
-            Real tn;
-            if (!box_enter(I.bmin, I.bmax, o, inv, tmin, tmax, tn)) continue;
-            bool rotated = false;
-            for (int k = 0; k < n_xf; ++k) {
-                const FXf& x = sc.fxf[I.xf_first + k];
-                wrapper_enter(x.type, x.f, lo, ld);
-                rotated |= x.type == RTR_NODE_ROTATE_Y;
+            if (use_boxes) {
+                Real tn;
+                if (!box_enter(I.bmin, I.bmax, o, inv, tmin, tmax, tn)) continue;
             }
-            if (rotated && I.bvh_root >= 0) linv = mk(1.0 / ld.x, 1.0 / ld.y, 1.0 / ld.z);
+            for (int k = 0; k < n_xf; ++k) {
+                const FXf x = ld_const(sc.fxf, I.xf_first + k);
+                wrapper_enter(x.type, x.f, lo, ld);
+            }
         }
+        if (I.bvh_root >= 0 && (n_xf || !use_boxes)) linv = mk(1.0 / ld.x, 1.0 / ld.y, 1.0 / ld.z);
         if (I.bvh_root < 0) {
             const int r0 = I.ref_first, r1 = r0 + I.n_ref;
             for (int r = r0; r < r1; ++r) {
@@ -573,14 +600,14 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, V3 o, V3 d, Real ti
  * tail in the instance frame, then the epilogues of the wrappers above it, innermost first. */
 template <bool UV>
 RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec) {
-    const FInst& I = sc.finst[inst];
-    const FRef& R = sc.fref[ref];
+    const FInst I = ld_const(sc.finst, inst);
+    const FRef R = ld_const(sc.fref, ref);
     V3 lo = o, ld = d;
     for (int k = 0; k < I.n_xf; ++k) {
-        const FXf& x = sc.fxf[I.xf_first + k];
+        const FXf x = ld_const(sc.fxf, I.xf_first + k);
         wrapper_enter(x.type, x.f, lo, ld);
     }
-    const rtr_node& n = sc.fprim[ref];
+    const rtr_node n = ld_const(sc.fprim, ref);
     const int type = n.type;
     if (type >= RTR_NODE_XY_RECT) {
         Real oa, da, ob, db;
@@ -602,12 +629,12 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
      * instance's first (n_xf - k) transform ops */
     int level = I.n_xf;
     for (int e = 0; e < R.n_exit; ++e) {
-        const rtr_node& w = sc.nodes[sc.fexit[R.exit_first + e]];
+        const rtr_node w = ld_const(sc.nodes, as_const(sc.fexit)[R.exit_first + e]);
         V3 wd = d;
         if (w.type != RTR_NODE_FLIP_FACE) {
             V3 wo = o;
             for (int k = 0; k < level; ++k) {
-                const FXf& x = sc.fxf[I.xf_first + k];
+                const FXf x = ld_const(sc.fxf, I.xf_first + k);
                 wrapper_enter(x.type, x.f, wo, wd);
             }
             --level;
