@@ -178,8 +178,11 @@ typedef struct rtr_scene_desc {
 /* render request                                                            */
 
 /* integrator ids follow the reference CLI (main.cpp:52,78-100) */
-#define RTR_INTEGRATOR_RR 1  /* RRPathInterator   renderer/rr_path_integrator.h:21-59  */
-#define RTR_INTEGRATOR_MIS 4 /* MISPathIntegrator renderer/mis_path_integrator.h:25-150 */
+#define RTR_INTEGRATOR_PATH 0 /* PathIntegrator        renderer/path_integrator.h:22-44 (summed front to back on the device) */
+#define RTR_INTEGRATOR_RR 1   /* RRPathInterator       renderer/rr_path_integrator.h:21-59  */
+#define RTR_INTEGRATOR_PBR 2  /* PBRPathIntegrator     renderer/pbr_path_integrator.h:21-73 */
+#define RTR_INTEGRATOR_NEE 3  /* DirectLightIntegrator renderer/direct_light_integrator.h:25-142 */
+#define RTR_INTEGRATOR_MIS 4  /* MISPathIntegrator     renderer/mis_path_integrator.h:25-150 */
 
 /* device pipeline selection */
 #define RTR_PIPELINE_AUTO 0

@@ -83,7 +83,9 @@ def main():
 
     # per-sample Li records and small images: (scene, integrator, W, spp, seed)
     cases = [(7, 1, 64, 16, 1), (7, 4, 64, 16, 1), (21, 4, 64, 16, 1), (23, 4, 64, 16, 1), (9, 1, 64, 16, 1),
-             (22, 4, 64, 16, 1)]
+             (22, 4, 64, 16, 1),
+             # integrators 0 (plain path), 2 (BSDF-only), 3 (NEE without MIS)
+             (7, 0, 48, 8, 1), (23, 2, 64, 16, 1), (21, 3, 64, 16, 1), (23, 3, 64, 16, 1)]
     for sid, integ, W, spp, seed in cases:
         name = "li_scene%02d_i%d.bin" % (sid, integ)
         cmd, info = run("li", sid, integ, W, spp, seed, SCENE_SEED, 2048, os.path.join(GOLD, name))

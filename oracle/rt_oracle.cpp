@@ -865,6 +865,126 @@ V3 li_rr(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g, Cou
     return L;
 }
 
+/* ---- renderer/path_integrator.h:22-44 (integrator id 0): recursion, depth 50, no roulette ----- */
+V3 li_path_rec(const Scene& sc, const Ray& r, int depth, Rng& g, Counters& cnt) {
+    Rec rec;
+    rec.u = rec.v = 0;
+    if (depth <= 0) return mk(0, 0, 0);
+    ++cnt.closest;
+    if (!hit_node(sc, sc.d->root, r, 0.001, kInf, rec, g)) return ld(sc.d->background);
+    Ray scattered;
+    V3 attenuation;
+    V3 emitted = mat_emitted_legacy(sc, rec);
+    if (!mat_scatter(sc, r, rec, attenuation, scattered, g)) return emitted;
+    return add(emitted, mul(attenuation, li_path_rec(sc, scattered, depth - 1, g, cnt)));
+}
+
+/* ---- renderer/pbr_path_integrator.h:21-73 (integrator id 2): BSDF sampling only --------------- */
+V3 li_pbr(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g, Counters& cnt) {
+    V3 throughput = mk(1.0, 1.0, 1.0);
+    V3 L = mk(0.0, 0.0, 0.0);
+    Ray current_ray = r;
+    const V3 background = ld(sc.d->background);
+    for (int depth = 0; depth < max_depth; ++depth) {
+        Rec rec;
+        rec.u = rec.v = 0;
+        ++cnt.closest;
+        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) {
+            L = add(L, mul(throughput, background));
+            break;
+        }
+        V3 wo = neg(unit(current_ray.d));
+        L = add(L, mul(throughput, mat_emitted(sc, rec)));
+        BSDFSample bs;
+        if (!mat_sample(sc, rec, wo, bs, g)) break;
+        if (bs.pdf < 1e-8 && !bs.is_specular) break;
+        double cos_theta = std::abs(dot(bs.wi, rec.normal));
+        if (bs.is_specular)
+            throughput = mul(throughput, bs.f);
+        else
+            throughput = mul(throughput, divs(scl(cos_theta, bs.f), bs.pdf));
+        current_ray = make_ray(rec.p, bs.wi, current_ray.tm);
+        if (depth >= rr_start) {
+            double p_survive = std::max({throughput.x, throughput.y, throughput.z});
+            p_survive = clampd(p_survive, 0.05, 0.95);
+            if (g.next() > p_survive) break;
+            throughput = divs(throughput, p_survive);
+        }
+    }
+    return L;
+}
+
+/* ---- renderer/direct_light_integrator.h:25-142 (integrator id 3): NEE without MIS -------------- */
+V3 sample_lights_direct(const Scene& sc, const Rec& rec, V3 wo, Rng& g, Counters& cnt) { /* :101-142 */
+    const int n_lights = sc.d->n_lights;
+    if (n_lights == 0) return mk(0, 0, 0);
+    V3 L_direct = mk(0, 0, 0);
+    int light_idx = g.irange(0, n_lights - 1);
+    const rtr_light& light = sc.d->lights[light_idx];
+    double light_pdf_sel = 1.0 / n_lights;
+    double uy = g.next();
+    double ux = g.next();
+    LightSample ls = light_sample(light, rec.p, ux, uy);
+    if (ls.pdf > 0 && len2(ls.Li) > 0) {
+        Ray shadow_ray = make_ray(rec.p, ls.wi, 0);
+        Rec shadow_rec;
+        ++cnt.shadow;
+        bool in_shadow = hit_node(sc, sc.d->root, shadow_ray, 0.001, ls.dist - 0.001, shadow_rec, g);
+        if (!in_shadow) {
+            V3 f = mat_eval(sc, rec, wo, ls.wi);
+            double cos_theta = std::abs(dot(ls.wi, rec.normal));
+            if (ls.is_delta)
+                L_direct = add(L_direct, divs(scl(cos_theta, mul(f, ls.Li)), light_pdf_sel));
+            else
+                L_direct = add(L_direct, divs(scl(cos_theta, mul(f, ls.Li)), ls.pdf * light_pdf_sel));
+        }
+    }
+    double max_radiance = 100.0; /* per-channel rescale, :133-139 */
+    if (L_direct.x > max_radiance) L_direct = scl(max_radiance / L_direct.x, L_direct);
+    if (L_direct.y > max_radiance) L_direct = scl(max_radiance / L_direct.y, L_direct);
+    if (L_direct.z > max_radiance) L_direct = scl(max_radiance / L_direct.z, L_direct);
+    return L_direct;
+}
+
+V3 li_direct(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g, Counters& cnt) { /* :38-98 */
+    V3 throughput = mk(1.0, 1.0, 1.0);
+    V3 L = mk(0.0, 0.0, 0.0);
+    Ray current_ray = r;
+    bool specular_bounce = false;
+    const bool have_lights = sc.d->n_lights > 0;
+    const V3 background = ld(sc.d->background);
+    for (int depth = 0; depth < max_depth; ++depth) {
+        Rec rec;
+        rec.u = rec.v = 0;
+        ++cnt.closest;
+        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) {
+            L = add(L, mul(throughput, background));
+            break;
+        }
+        V3 wo = neg(unit(current_ray.d));
+        if (depth == 0 || specular_bounce) L = add(L, mul(throughput, mat_emitted(sc, rec)));
+        specular_bounce = false; /* material::is_specular() */
+        if (!specular_bounce && have_lights) L = add(L, mul(throughput, sample_lights_direct(sc, rec, wo, g, cnt)));
+        BSDFSample bs;
+        if (!mat_sample(sc, rec, wo, bs, g)) break;
+        if (bs.pdf < 1e-8 && !bs.is_specular) break;
+        specular_bounce = bs.is_specular;
+        double cos_theta = std::abs(dot(bs.wi, rec.normal));
+        if (bs.is_specular)
+            throughput = mul(throughput, bs.f);
+        else
+            throughput = mul(throughput, divs(scl(cos_theta, bs.f), bs.pdf));
+        current_ray = make_ray(rec.p, bs.wi, current_ray.tm);
+        if (depth >= rr_start) {
+            double p_survive = std::max({throughput.x, throughput.y, throughput.z});
+            p_survive = clampd(p_survive, 0.05, 0.95);
+            if (g.next() > p_survive) break;
+            throughput = divs(throughput, p_survive);
+        }
+    }
+    return L;
+}
+
 /* one camera sample: renderer/renderer.h:73-78 under the seeded RNG */
 V3 camera_sample(const Scene& sc, const rtr_render_params& p, int i, int j, int s, uint32_t* rng_exit,
                  Counters& cnt) {
@@ -872,8 +992,14 @@ V3 camera_sample(const Scene& sc, const rtr_render_params& p, int i, int j, int 
     double u = (i + g.next()) / (p.image_width - 1);
     double v = (j + g.next()) / (p.image_height - 1);
     Ray r = camera_get_ray(sc.d->camera, u, v, g);
-    V3 L = p.integrator == RTR_INTEGRATOR_RR ? li_rr(sc, r, p.max_depth, p.rr_start_depth, g, cnt)
-                                             : li_mis(sc, r, p.max_depth, p.rr_start_depth, g, cnt);
+    V3 L;
+    switch (p.integrator) {
+    case RTR_INTEGRATOR_PATH: L = li_path_rec(sc, r, p.max_depth, g, cnt); break;
+    case RTR_INTEGRATOR_RR: L = li_rr(sc, r, p.max_depth, p.rr_start_depth, g, cnt); break;
+    case RTR_INTEGRATOR_PBR: L = li_pbr(sc, r, p.max_depth, p.rr_start_depth, g, cnt); break;
+    case RTR_INTEGRATOR_NEE: L = li_direct(sc, r, p.max_depth, p.rr_start_depth, g, cnt); break;
+    default: L = li_mis(sc, r, p.max_depth, p.rr_start_depth, g, cnt); break;
+    }
     if (rng_exit) *rng_exit = g.s;
     return L;
 }
@@ -881,7 +1007,7 @@ V3 camera_sample(const Scene& sc, const rtr_render_params& p, int i, int j, int 
 bool params_ok(const rtr_scene_desc* sc, const rtr_render_params* p) {
     if (!sc || !p || sc->root < 0 || sc->root >= sc->n_nodes) return false;
     if (p->image_width < 2 || p->image_height < 2 || p->spp < 1) return false;
-    if (p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS) return false;
+    if (p->integrator < RTR_INTEGRATOR_PATH || p->integrator > RTR_INTEGRATOR_MIS) return false;
     return true;
 }
 

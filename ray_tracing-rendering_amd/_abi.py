@@ -22,8 +22,7 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_PBR, MAT_ISOTR
 TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(4)
 LIGHT_QUAD = 0
 
-INTEGRATOR_RR = 1
-INTEGRATOR_MIS = 4
+INTEGRATOR_PATH, INTEGRATOR_RR, INTEGRATOR_PBR, INTEGRATOR_NEE, INTEGRATOR_MIS = 0, 1, 2, 3, 4
 PIPELINE_AUTO, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1, 2
 FLAG_REFERENCE_ORDER = 1
 

@@ -1126,23 +1126,36 @@ struct ShadowReq {
  * shadow test (the reference evaluates them after it; they draw no random numbers), so the
  * connection can be resolved later by a separate shadow-ray stage.
  */
-template <int MS = RT_MS_FULL>
+/* The same two halves serve three integrators (INTEG):
+ *   RTR_INTEGRATOR_MIS  mis_path_integrator.h:69-146   (MIS-weighted emission + light sample, scatter() fallback)
+ *   RTR_INTEGRATOR_NEE  direct_light_integrator.h:56-95 (emission only at depth 0 / after specular, light sample
+ *                       without MIS weight and with the per-channel rescale of :133-139, no fallback)
+ *   RTR_INTEGRATOR_PBR  pbr_path_integrator.h:38-68     (emission unweighted, no light sample, no fallback) */
+template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS>
 RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, ShadowReq& rq) {
     const bool have_lights = sc.n_lights > 0;
-    V3 emitted = mat_emitted<MS>(sc, rec);
-    if (len2(emitted) > 0) { /* :72-94 */
-        V3 L_emit;
-        if (ps.depth == 0 || ps.specular_bounce) {
-            L_emit = mul(ps.thr, emitted);
-        } else if (have_lights) {
-            Real mis_weight = power_heuristic(ps.prev_bsdf_pdf, compute_light_pdf(sc, ps.ro, ps.rd));
-            L_emit = scl(mis_weight, mul(ps.thr, emitted));
-        } else {
-            L_emit = mul(ps.thr, emitted);
-        }
-        ps.L = add(ps.L, ps.depth == 0 ? L_emit : clamp_radiance(L_emit));
-    }
     rq.valid = false;
+    if (INTEG == RTR_INTEGRATOR_PBR) {
+        ps.L = add(ps.L, mul(ps.thr, mat_emitted<MS>(sc, rec))); /* pbr_path_integrator.h:40-41 */
+        return;
+    }
+    if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:56-59 */
+        if (ps.depth == 0 || ps.specular_bounce) ps.L = add(ps.L, mul(ps.thr, mat_emitted<MS>(sc, rec)));
+    } else {
+        V3 emitted = mat_emitted<MS>(sc, rec);
+        if (len2(emitted) > 0) { /* mis_path_integrator.h:72-94 */
+            V3 L_emit;
+            if (ps.depth == 0 || ps.specular_bounce) {
+                L_emit = mul(ps.thr, emitted);
+            } else if (have_lights) {
+                Real mis_weight = power_heuristic(ps.prev_bsdf_pdf, compute_light_pdf(sc, ps.ro, ps.rd));
+                L_emit = scl(mis_weight, mul(ps.thr, emitted));
+            } else {
+                L_emit = mul(ps.thr, emitted);
+            }
+            ps.L = add(ps.L, ps.depth == 0 ? L_emit : clamp_radiance(L_emit));
+        }
+    }
     /* material::is_specular() is never overridden, so NEE runs at every hit */
     if (have_lights) {
         const int light_idx = rng_int(rng, 0, sc.n_lights - 1);
@@ -1154,24 +1167,34 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
             V3 f = mat_eval<MS>(sc, rec, wo, ls.wi);
             Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));
-            Real bsdf_pdf = mat_pdf<MS>(sc, rec, wo, ls.wi);
-            Real lpdf = ls.pdf * light_select_pdf;
-            Real mis_weight = power_heuristic(lpdf, bsdf_pdf);
-            V3 L_direct = divs(scl(mis_weight, scl(cos_theta, mul(f, ls.Li))), lpdf);
+            V3 L_direct;
+            if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:125-139 */
+                L_direct = divs(scl(cos_theta, mul(f, ls.Li)), ls.pdf * light_select_pdf);
+                const Real max_radiance = 100.0;
+                if (L_direct.x > max_radiance) L_direct = scl(max_radiance / L_direct.x, L_direct);
+                if (L_direct.y > max_radiance) L_direct = scl(max_radiance / L_direct.y, L_direct);
+                if (L_direct.z > max_radiance) L_direct = scl(max_radiance / L_direct.z, L_direct);
+            } else { /* mis_path_integrator.h:215-229 */
+                Real bsdf_pdf = mat_pdf<MS>(sc, rec, wo, ls.wi);
+                Real lpdf = ls.pdf * light_select_pdf;
+                Real mis_weight = power_heuristic(lpdf, bsdf_pdf);
+                L_direct = divs(scl(mis_weight, scl(cos_theta, mul(f, ls.Li))), lpdf);
+            }
             rq.valid = true;
             rq.wi = ls.wi;
             rq.tmax = ls.dist - 0.001;
-            rq.contrib = clamp_radiance(mul(ps.thr, L_direct));
+            rq.contrib = INTEG == RTR_INTEGRATOR_NEE ? mul(ps.thr, L_direct) : clamp_radiance(mul(ps.thr, L_direct));
         }
     }
 }
 
 /* second half (mis_path_integrator.h:105-146): BSDF sampling with the legacy scatter()
- * fallback, throughput update, Russian roulette.  Returns false when the path ends. */
-template <int MS = RT_MS_FULL>
+ * fallback (MIS only), throughput update, Russian roulette.  Returns false when the path ends. */
+template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS>
 RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, int rr_start) {
     BSDFSample bs;
     if (!mat_sample<MS>(sc, rec, wo, bs, rng)) { /* :106-118 */
+        if (INTEG != RTR_INTEGRATOR_MIS) return false; /* pbr_path_integrator.h:44-46, direct_light_integrator.h:67-69 */
         V3 attenuation, ndir;
         if (!mat_scatter<MS>(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
         ps.thr = mul(ps.thr, attenuation);
@@ -1214,6 +1237,19 @@ RT_DEV bool shade_rr(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& 
     return true;
 }
 
+/* PathIntegrator (path_integrator.h:22-44): the reference recurses, emitted + attenuation * Li(next);
+ * here the same terms are summed front to back (throughput-weighted), which differs only in
+ * rounding (<= 1e-15 relative).  No roulette; depth limited by max_depth. */
+template <int MS = RT_MS_FULL>
+RT_DEV bool shade_path(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& rng) {
+    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy<MS>(sc, rec)));
+    V3 attenuation, ndir;
+    if (!mat_scatter<MS>(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+    ps.thr = mul(ps.thr, attenuation);
+    ps.ro = rec.p, ps.rd = ndir;
+    return true;
+}
+
 /*
  * One whole loop iteration of Integrator::Li in registers (megakernel / unit tests):
  * closest hit, shading, inline shadow ray.  Returns false when the camera sample is
@@ -1231,17 +1267,22 @@ __device__ __forceinline__ bool bounce(const DScene& sc, PathState& ps, uint32_t
         return false;
     }
     bool go;
-    if (INTEG == RTR_INTEGRATOR_MIS) {
+    if (INTEG == RTR_INTEGRATOR_RR) {
+        go = shade_rr(sc, ps, rec, rng, rr_start);
+    } else if (INTEG == RTR_INTEGRATOR_PATH) {
+        go = shade_path(sc, ps, rec, rng);
+        if (!go) return false;
+        if (++ps.depth < max_depth) return true;
+        return false; /* path_integrator.h:27-29: the call at depth 0 contributes nothing */
+    } else {
         V3 wo = neg(unit(ps.rd));
         ShadowReq rq;
-        shade_a_mis(sc, ps, rec, wo, rng, rq);
+        shade_a_mis<RT_MS_FULL, INTEG>(sc, ps, rec, wo, rng, rq);
         if (rq.valid) {
             ++cnt.shadow;
             if (!cast_shadow<TRAV>(sc, rec.p, rq.wi, rq.tmax, rng, st)) ps.L = add(ps.L, rq.contrib);
         } /* else the reference adds clamp_radiance(throughput * 0) = +0 (:99-103): no effect */
-        go = shade_b_mis(sc, ps, rec, wo, rng, rr_start);
-    } else {
-        go = shade_rr(sc, ps, rec, rng, rr_start);
+        go = shade_b_mis<RT_MS_FULL, INTEG>(sc, ps, rec, wo, rng, rr_start);
     }
     if (!go) return false;
     return ++ps.depth < max_depth;

@@ -144,18 +144,20 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                     ps.L = pk.get3(PK_L);
                     ps.prev_bsdf_pdf = pk.get(PK_PDF);
                     bool go;
-                    if (INTEG == RTR_INTEGRATOR_MIS) {
+                    if (INTEG == RTR_INTEGRATOR_RR) {
+                        go = shade_rr<MS>(sc, ps, rec, rng, P.rr_start);
+                    } else if (INTEG == RTR_INTEGRATOR_PATH) {
+                        go = shade_path<MS>(sc, ps, rec, rng);
+                    } else {
                         const V3 wo = neg(unit(ps.rd));
                         ShadowReq rq;
-                        shade_a_mis<MS>(sc, ps, rec, wo, rng, rq);
+                        shade_a_mis<MS, INTEG>(sc, ps, rec, wo, rng, rq);
                         if (rq.valid) {
                             pending = true;
                             swi = rq.wi, stmax = rq.tmax;
                             pk.set3(PK_CONTRIB, rq.contrib);
                         }
-                        go = shade_b_mis<MS>(sc, ps, rec, wo, rng, P.rr_start);
-                    } else {
-                        go = shade_rr<MS>(sc, ps, rec, rng, P.rr_start);
+                        go = shade_b_mis<MS, INTEG>(sc, ps, rec, wo, rng, P.rr_start);
                     }
                     ps.ro = rec.p; /* next ray origin and shadow ray origin */
                     pk.set3(PK_THR, ps.thr);

@@ -268,8 +268,8 @@ int params_check(rtr_context* c, const rtr_render_params* p) {
         return fail(c, RTR_ERR_INVALID, "region outside the image or empty");
     if (p->spp < 1 || p->max_depth < 1 || p->rr_start_depth < 0)
         return fail(c, RTR_ERR_INVALID, "spp/max_depth/rr_start_depth out of range");
-    if (p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS)
-        return fail(c, RTR_ERR_UNSUPPORTED, "integrator id not supported (1 = RR, 4 = MIS)");
+    if (p->integrator < RTR_INTEGRATOR_PATH || p->integrator > RTR_INTEGRATOR_MIS)
+        return fail(c, RTR_ERR_UNSUPPORTED, "integrator id not supported (0 path, 1 RR, 2 PBR, 3 NEE, 4 MIS)");
     if (p->tile_stride > 1 && (p->tile_first < 0 || p->tile_first >= p->tile_stride))
         return fail(c, RTR_ERR_INVALID, "tile_first must be in [0, tile_stride)");
     if (p->spp_chunks < 0 || p->spp_chunks > p->spp) return fail(c, RTR_ERR_INVALID, "spp_chunks must be in [0, spp]");
@@ -344,10 +344,23 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
                 RTR_LAUNCH(I, RT_TRAV_EXACT, RT_MS_FULL);                   \
         }                                                                   \
     } while (0)
-    if (integrator == RTR_INTEGRATOR_MIS)
-        RTR_LAUNCH_T(RTR_INTEGRATOR_MIS);
-    else
-        RTR_LAUNCH_T(RTR_INTEGRATOR_RR);
+/* integrators 0 / 2 / 3: generic material set; the media kernel also serves the
+ * reference-order traversal of scenes without media */
+#define RTR_LAUNCH_N1(I)                                   \
+    do {                                                   \
+        if (trav == RT_TRAV_FAST)                          \
+            RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);       \
+        else                                               \
+            RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);      \
+    } while (0)
+    switch (integrator) {
+    case RTR_INTEGRATOR_MIS: RTR_LAUNCH_T(RTR_INTEGRATOR_MIS); break;
+    case RTR_INTEGRATOR_RR: RTR_LAUNCH_T(RTR_INTEGRATOR_RR); break;
+    case RTR_INTEGRATOR_PATH: RTR_LAUNCH_N1(RTR_INTEGRATOR_PATH); break;
+    case RTR_INTEGRATOR_PBR: RTR_LAUNCH_N1(RTR_INTEGRATOR_PBR); break;
+    default: RTR_LAUNCH_N1(RTR_INTEGRATOR_NEE); break;
+    }
+#undef RTR_LAUNCH_N1
 #undef RTR_LAUNCH_T
 #undef RTR_LAUNCH
     HIPCHK(c, hipGetLastError());
@@ -562,6 +575,8 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
 
     int pipeline = p->pipeline;
     if (pipeline == RTR_PIPELINE_AUTO) pipeline = RTR_PIPELINE_MEGAKERNEL;
+    if (pipeline == RTR_PIPELINE_WAVEFRONT && p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS)
+        return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs integrators 1 (RR) and 4 (MIS) only");
     const int trav = pick_trav(c, p->flags);
     /* auto chunking: aim for >= 4096 workgroups so the 256 CUs stay fed through the tail */
     int chunks = p->spp_chunks;
@@ -753,10 +768,21 @@ int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs,
         else                                                   \
             RTR_LAUNCH(I, RT_TRAV_EXACT);                      \
     } while (0)
-    if (p->integrator == RTR_INTEGRATOR_MIS)
-        RTR_LAUNCH_T(RTR_INTEGRATOR_MIS);
-    else
-        RTR_LAUNCH_T(RTR_INTEGRATOR_RR);
+#define RTR_LAUNCH_N1(I)                                   \
+    do {                                                   \
+        if (trav == RT_TRAV_FAST)                          \
+            RTR_LAUNCH(I, RT_TRAV_FAST);                   \
+        else                                               \
+            RTR_LAUNCH(I, RT_TRAV_MEDIA);                  \
+    } while (0)
+    switch (p->integrator) {
+    case RTR_INTEGRATOR_MIS: RTR_LAUNCH_T(RTR_INTEGRATOR_MIS); break;
+    case RTR_INTEGRATOR_RR: RTR_LAUNCH_T(RTR_INTEGRATOR_RR); break;
+    case RTR_INTEGRATOR_PATH: RTR_LAUNCH_N1(RTR_INTEGRATOR_PATH); break;
+    case RTR_INTEGRATOR_PBR: RTR_LAUNCH_N1(RTR_INTEGRATOR_PBR); break;
+    default: RTR_LAUNCH_N1(RTR_INTEGRATOR_NEE); break;
+    }
+#undef RTR_LAUNCH_N1
 #undef RTR_LAUNCH_T
 #undef RTR_LAUNCH
     return test_end(c, recs, n, sizeof *recs);

@@ -4,7 +4,7 @@
  * overrides the BASELINE configurations need (--width --spp --seed --out).  It is the
  * reference-side usage of the host layer: select_scene -> camera -> Renderer::render -> file.
  *
- *   rtr_cli <scene 7|9|21|22|23> <integrator 1|4> [--width W] [--spp N] [--seed S] [--out img.ppm]
+ *   rtr_cli <scene 7|9|21|22|23> <integrator 0..4> [--width W] [--spp N] [--seed S] [--out img.ppm]
  */
 #include "rtr_renderer.h"
 
@@ -39,13 +39,12 @@ int main(int argc, char** argv) {
     RenderBuffer buffer(W, H);
     Renderer renderer;
     renderer.set_samples(config.samples_per_pixel);
-    if (integrator_id == 1)
-        renderer.set_integrator(make_shared<RRPathInterator>());
-    else if (integrator_id == 4)
-        renderer.set_integrator(make_shared<MISPathIntegrator>());
-    else {
-        std::cerr << "integrator " << integrator_id << " is not on the device (1 = RR, 4 = MIS)\n";
-        return 2;
+    switch (integrator_id) { /* main.cpp:80-100 */
+    case 0: renderer.set_integrator(make_shared<PathIntegrator>()); break;
+    case 1: renderer.set_integrator(make_shared<RRPathInterator>()); break;
+    case 2: renderer.set_integrator(make_shared<PBRPathIntegrator>()); break;
+    case 3: renderer.set_integrator(make_shared<DirectLightIntegrator>()); break;
+    default: renderer.set_integrator(make_shared<MISPathIntegrator>()); break;
     }
     renderer.set_max_depth(50); /* main.cpp:102 */
     renderer.set_seed(seed);

@@ -82,6 +82,40 @@ class RRPathInterator : public Integrator { /* sic: the reference's spelling */
     int m_max_depth = 50, m_rr_start_depth = 3;
 };
 
+/* the other three integrators of the reference CLI (main.cpp:72-76), megakernel only */
+class PathIntegrator : public Integrator { /* renderer/path_integrator.h */
+  public:
+    void set_max_depth(int depth = 50) override { m_max_depth = depth; }
+    int rtr_integrator_id() const override { return RTR_INTEGRATOR_PATH; }
+    int rtr_max_depth() const override { return m_max_depth; }
+    int rtr_rr_start() const override { return 3; }
+
+  private:
+    int m_max_depth = 50;
+};
+class PBRPathIntegrator : public Integrator { /* renderer/pbr_path_integrator.h */
+  public:
+    void set_max_depth(int depth = 50) override { m_max_depth = depth; }
+    void set_rr_start_depth(int depth) { m_rr_start_depth = depth; }
+    int rtr_integrator_id() const override { return RTR_INTEGRATOR_PBR; }
+    int rtr_max_depth() const override { return m_max_depth; }
+    int rtr_rr_start() const override { return m_rr_start_depth; }
+
+  private:
+    int m_max_depth = 50, m_rr_start_depth = 3;
+};
+class DirectLightIntegrator : public Integrator { /* renderer/direct_light_integrator.h */
+  public:
+    void set_max_depth(int depth = 50) override { m_max_depth = depth; }
+    void set_rr_start_depth(int depth) { m_rr_start_depth = depth; }
+    int rtr_integrator_id() const override { return RTR_INTEGRATOR_NEE; }
+    int rtr_max_depth() const override { return m_max_depth; }
+    int rtr_rr_start() const override { return m_rr_start_depth; }
+
+  private:
+    int m_max_depth = 50, m_rr_start_depth = 3;
+};
+
 class Renderer {
   public:
     struct Settings {

@@ -95,7 +95,7 @@ def test_light_vectors(sid):
     assert (gold["pdf"] > 0).any() and (gold["pdf"] == 0).any()
 
 
-LI_CASES = [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4)]
+LI_CASES = [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4), (7, 0), (23, 2), (21, 3), (23, 3)]
 
 
 @pytest.mark.parametrize("sid,integ", LI_CASES)
@@ -117,7 +117,8 @@ def test_li_records(sid, integ):
 
 IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_scene21_i4_64_spp16.f64",
              "img_scene23_i4_64_spp16.f64", "img_scene09_i1_64_spp16.f64", "img_scene22_i4_64_spp16.f64",
-             "img_scene21_i4_128_spp32.f64"]
+             "img_scene21_i4_128_spp32.f64", "img_scene07_i0_48_spp8.f64", "img_scene23_i2_64_spp16.f64",
+             "img_scene21_i3_64_spp16.f64", "img_scene23_i3_64_spp16.f64"]
 
 
 @pytest.mark.parametrize("name", IMG_CASES)
