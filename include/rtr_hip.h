@@ -126,8 +126,11 @@ typedef struct rtr_image {
 
 /* lights (lighting/light.h:15-47) */
 typedef enum rtr_light_type {
-    RTR_LIGHT_QUAD = 0, /* QuadLight lighting/quad_light.h:9-92: f[0..2]=Q f[3..5]=u f[6..8]=v f[9..11]=intensity f[12..14]=normal f[15]=area */
-    RTR_LIGHT_TYPE_COUNT = 1
+    RTR_LIGHT_QUAD = 0,        /* QuadLight lighting/quad_light.h:9-92: f[0..2]=Q f[3..5]=u f[6..8]=v f[9..11]=intensity f[12..14]=normal f[15]=area */
+    RTR_LIGHT_POINT = 1,       /* PointLight lighting/point_light.h:6-37: f[0..2]=position f[3..5]=intensity */
+    RTR_LIGHT_SPOT = 2,        /* SpotLight lighting/spot_light.h:6-41: f[0..2]=position f[3..5]=unit direction f[6..8]=intensity f[9]=cos_cutoff */
+    RTR_LIGHT_DIRECTIONAL = 3, /* DirectionalLight lighting/directional_light.h:7-31: f[0..2]=unit direction f[3..5]=radiance */
+    RTR_LIGHT_TYPE_COUNT = 4
 } rtr_light_type;
 
 typedef struct rtr_light {

@@ -265,6 +265,20 @@ struct Flattener {
             put3(r.f + 9, q->intensity);
             put3(r.f + 12, q->normal);
             r.f[15] = q->area;
+        } else if (auto pl = dynamic_cast<const PointLight*>(l)) {
+            r.type = RTR_LIGHT_POINT;
+            put3(r.f, pl->m_position);
+            put3(r.f + 3, pl->m_intensity);
+        } else if (auto sl = dynamic_cast<const SpotLight*>(l)) {
+            r.type = RTR_LIGHT_SPOT;
+            put3(r.f, sl->position);
+            put3(r.f + 3, sl->direction);
+            put3(r.f + 6, sl->intensity);
+            r.f[9] = sl->cos_cutoff;
+        } else if (auto dl = dynamic_cast<const DirectionalLight*>(l)) {
+            r.type = RTR_LIGHT_DIRECTIONAL;
+            put3(r.f, dl->direction);
+            put3(r.f + 3, dl->L);
         } else {
             die("unsupported light class in reference scene");
         }

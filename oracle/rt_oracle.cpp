@@ -657,8 +657,41 @@ struct LightSample {
     double pdf, dist;
     bool is_delta;
 };
-LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy) { /* quad_light.h:18-48 */
+LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy) {
     LightSample s;
+    if (l.type == RTR_LIGHT_POINT) { /* point_light.h:12-22 */
+        V3 direction = sub(ld(l.f), p);
+        double dist_squared = len2(direction);
+        s.dist = std::sqrt(dist_squared);
+        s.wi = divs(direction, s.dist);
+        s.Li = divs(ld(l.f + 3), dist_squared);
+        s.pdf = 1.0;
+        s.is_delta = true;
+        return s;
+    }
+    if (l.type == RTR_LIGHT_SPOT) { /* spot_light.h:14-32 */
+        V3 d = sub(ld(l.f), p);
+        double dist2 = len2(d);
+        s.dist = std::sqrt(dist2);
+        s.wi = divs(d, s.dist);
+        s.is_delta = true;
+        s.pdf = 1.0;
+        double cos_theta = dot(neg(s.wi), ld(l.f + 3));
+        if (cos_theta < l.f[9])
+            s.Li = mk(0, 0, 0);
+        else
+            s.Li = divs(ld(l.f + 6), dist2);
+        return s;
+    }
+    if (l.type == RTR_LIGHT_DIRECTIONAL) { /* directional_light.h:13-21 */
+        s.wi = neg(ld(l.f));
+        s.dist = kInf;
+        s.Li = ld(l.f + 3);
+        s.is_delta = true;
+        s.pdf = 1.0;
+        return s;
+    }
+    /* quad_light.h:18-48 */
     V3 Q = ld(l.f), U = ld(l.f + 3), Vv = ld(l.f + 6), normal = ld(l.f + 12);
     double area = l.f[15];
     V3 light_point = add(add(Q, scl(ux, U)), scl(uy, Vv));
@@ -678,6 +711,7 @@ LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy) { /* qu
     return s;
 }
 double light_pdf(const rtr_light& l, V3 origin, V3 direction) { /* quad_light.h:50-77 */
+    if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf base (light.h:26-28): delta lights */
     V3 Q = ld(l.f), U = ld(l.f + 3), Vv = ld(l.f + 6), normal = ld(l.f + 12);
     double area = l.f[15];
     double denom = dot(direction, normal);

@@ -1021,9 +1021,35 @@ __device__ __forceinline__ bool mat_scatter(const DScene& sc, V3 rd, const Hit& 
 struct LightSample {
     V3 Li, wi;
     Real pdf, dist;
+    bool is_delta;
 };
 RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy) {
     LightSample s;
+    const int type = l.type;
+    if (type != RTR_LIGHT_QUAD) {
+        s.is_delta = true;
+        s.pdf = 1.0;
+        if (type == RTR_LIGHT_DIRECTIONAL) { /* lighting/directional_light.h:13-21 */
+            s.wi = neg(ld3(l.f));
+            s.dist = RT_INF;
+            s.Li = ld3(l.f + 3);
+            return s;
+        }
+        /* lighting/point_light.h:12-22, spot_light.h:14-32 */
+        V3 d = sub(ld3(l.f), p);
+        Real dist2 = len2(d);
+        s.dist = __builtin_sqrt(dist2);
+        s.wi = divs(d, s.dist);
+        if (type == RTR_LIGHT_POINT) {
+            s.Li = divs(ld3(l.f + 3), dist2);
+        } else {
+            Real cos_theta = dot(neg(s.wi), ld3(l.f + 3));
+            s.Li = cos_theta < l.f[9] ? mk(0, 0, 0) : divs(ld3(l.f + 6), dist2);
+        }
+        return s;
+    }
+    /* lighting/quad_light.h:18-48 */
+    s.is_delta = false;
     V3 light_point = add(add(ld3(l.f), scl(ux, ld3(l.f + 3))), scl(uy, ld3(l.f + 6)));
     V3 d = sub(light_point, p);
     Real dist_sq = len2(d);
@@ -1040,6 +1066,7 @@ RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy) {
     return s;
 }
 RT_DEV Real light_pdf(const rtr_light& l, V3 origin, V3 direction) {
+    if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf (light.h:26-28): delta lights */
     V3 Q = ld3(l.f), U = ld3(l.f + 3), Vv = ld3(l.f + 6), normal = ld3(l.f + 12);
     Real denom = dot(direction, normal);
     if (denom >= -1e-6) return 0;
@@ -1169,12 +1196,14 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
             Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));
             V3 L_direct;
             if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:125-139 */
-                L_direct = divs(scl(cos_theta, mul(f, ls.Li)), ls.pdf * light_select_pdf);
+                L_direct = divs(scl(cos_theta, mul(f, ls.Li)), ls.is_delta ? light_select_pdf : ls.pdf * light_select_pdf);
                 const Real max_radiance = 100.0;
                 if (L_direct.x > max_radiance) L_direct = scl(max_radiance / L_direct.x, L_direct);
                 if (L_direct.y > max_radiance) L_direct = scl(max_radiance / L_direct.y, L_direct);
                 if (L_direct.z > max_radiance) L_direct = scl(max_radiance / L_direct.z, L_direct);
-            } else { /* mis_path_integrator.h:215-229 */
+            } else if (ls.is_delta) { /* mis_path_integrator.h:219-221: no BSDF sample can hit a delta light */
+                L_direct = divs(scl(cos_theta, mul(f, ls.Li)), light_select_pdf);
+            } else { /* mis_path_integrator.h:222-229 */
                 Real bsdf_pdf = mat_pdf<MS>(sc, rec, wo, ls.wi);
                 Real lpdf = ls.pdf * light_select_pdf;
                 Real mis_weight = power_heuristic(lpdf, bsdf_pdf);

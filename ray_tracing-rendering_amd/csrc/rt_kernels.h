@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_lights(const DScene sc, rtr_
     LightSample s = light_sample(l, ld3(r.p), r.u[0], r.u[1]);
     r.Li[0] = s.Li.x, r.Li[1] = s.Li.y, r.Li[2] = s.Li.z;
     r.wi[0] = s.wi.x, r.wi[1] = s.wi.y, r.wi[2] = s.wi.z;
-    r.pdf = s.pdf, r.dist = s.dist, r.is_delta = 0, r.pad2 = 0;
+    r.pdf = s.pdf, r.dist = s.dist, r.is_delta = s.is_delta, r.pad2 = 0;
     r.pdf_dir = light_pdf(l, ld3(r.p), ld3(r.dir));
     recs[k] = r;
 }

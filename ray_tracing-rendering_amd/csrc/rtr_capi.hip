@@ -240,8 +240,8 @@ struct Validator {
             (s->n_image_bytes && !s->image_bytes) || (s->n_lights && !s->lights))
             return (bad(RTR_ERR_INVALID, "null array with non-zero count"), code);
         for (int k = 0; k < s->n_lights; ++k)
-            if (s->lights[k].type != RTR_LIGHT_QUAD)
-                return (bad(RTR_ERR_UNSUPPORTED, "only QuadLight is supported on the device"), code);
+            if (s->lights[k].type < 0 || s->lights[k].type >= RTR_LIGHT_TYPE_COUNT)
+                return (bad(RTR_ERR_UNSUPPORTED, "unknown light type (QuadLight, PointLight, SpotLight, DirectionalLight are on the device)"), code);
         state.assign(s->n_nodes, 0);
         need.assign(s->n_nodes, 0);
         depth.assign(s->n_nodes, 0);

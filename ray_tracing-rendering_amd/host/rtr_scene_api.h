@@ -630,15 +630,16 @@ class QuadLight : public Light { /* lighting/quad_light.h:9-17 */
     double area;
 };
 
-/* Delta lights and the HDR environment light are scene-description placeholders for now
- * (SURVEY 8f N2): they construct, but flatten() refuses scenes that use them. */
+/* delta lights (lighting/point_light.h, spot_light.h, directional_light.h) */
 class PointLight : public Light {
   public:
     PointLight(const point3& pos, const color& intensity) : m_position(pos), m_intensity(intensity) {}
     bool is_delta() const override { return true; }
-    bool rtr_flatten(rtr_light&, std::string& why) const override {
-        why = "PointLight is not on the device yet (SURVEY 8f N2)";
-        return false;
+    bool rtr_flatten(rtr_light& out, std::string&) const override {
+        out = rtr_light{};
+        out.type = RTR_LIGHT_POINT;
+        for (int c = 0; c < 3; ++c) out.f[c] = m_position[c], out.f[3 + c] = m_intensity[c];
+        return true;
     }
     point3 m_position;
     color m_intensity;
@@ -646,11 +647,17 @@ class PointLight : public Light {
 class SpotLight : public Light {
   public:
     SpotLight(point3 pos, vec3 dir, double cutoff, color intensity_)
-        : position(pos), direction(unit_vector(dir)), intensity(intensity_), cos_cutoff(cos(cutoff * (pi / 180.0))) {}
+        : position(pos), direction(unit_vector(dir)), intensity(intensity_) {
+        const double r = cutoff * (pi / 180.0); /* spot_light.h:10-11 */
+        cos_cutoff = cos(r);
+    }
     bool is_delta() const override { return true; }
-    bool rtr_flatten(rtr_light&, std::string& why) const override {
-        why = "SpotLight is not on the device yet (SURVEY 8f N2)";
-        return false;
+    bool rtr_flatten(rtr_light& out, std::string&) const override {
+        out = rtr_light{};
+        out.type = RTR_LIGHT_SPOT;
+        for (int c = 0; c < 3; ++c) out.f[c] = position[c], out.f[3 + c] = direction[c], out.f[6 + c] = intensity[c];
+        out.f[9] = cos_cutoff;
+        return true;
     }
     point3 position;
     vec3 direction;
@@ -661,13 +668,17 @@ class DirectionalLight : public Light {
   public:
     DirectionalLight(const vec3& dir, const color& c) : direction(unit_vector(dir)), L(c) {}
     bool is_delta() const override { return true; }
-    bool rtr_flatten(rtr_light&, std::string& why) const override {
-        why = "DirectionalLight is not on the device yet (SURVEY 8f N2)";
-        return false;
+    bool rtr_flatten(rtr_light& out, std::string&) const override {
+        out = rtr_light{};
+        out.type = RTR_LIGHT_DIRECTIONAL;
+        for (int c = 0; c < 3; ++c) out.f[c] = direction[c], out.f[3 + c] = L[c];
+        return true;
     }
     vec3 direction;
     color L;
 };
+/* The HDR environment light is a scene-description placeholder for now: it
+ * constructs, but flatten() refuses scenes that use it. */
 class EnvironmentLight : public Light {
   public:
     EnvironmentLight(const char* map_filename) : filename(map_filename ? map_filename : "") {}

@@ -69,7 +69,7 @@ def test_validate_rejects_malformed_scenes():
     expect(_mutated(21, lambda s: s.nodes["type"].__setitem__(s.root, 77)), A.RTR_ERR_UNSUPPORTED, "node type")
     expect(_mutated(21, lambda s: s.materials["type"].__setitem__(0, 9)), A.RTR_ERR_UNSUPPORTED, "material type")
     expect(_mutated(21, lambda s: s.materials["tex"].__setitem__((0, 0), 50)), A.RTR_ERR_INVALID, "texture index")
-    expect(_mutated(21, lambda s: s.lights["type"].__setitem__(0, 3)), A.RTR_ERR_UNSUPPORTED, "QuadLight")
+    expect(_mutated(21, lambda s: s.lights["type"].__setitem__(0, 9)), A.RTR_ERR_UNSUPPORTED, "light type")
 
     def cycle(s):  # make a bvh node its own child
         s.nodes["a"][s.root] = s.root

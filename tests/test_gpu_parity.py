@@ -279,6 +279,36 @@ def test_next_integrators(ctx, sid, integ, img_name):
     assert e.value.code == A.RTR_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("sid", [15, 17, 18])
+def test_delta_lights(ctx, sid):
+    """PointLight (scene 15), DirectionalLight (17), SpotLight (18): light records,
+    per-sample records and images vs the reference, both pipelines."""
+    sc = _upload(ctx, sid)
+    gold = G.records("lights_scene%02d.bin" % sid, A.LIGHTREC_DTYPE)
+    out = ctx.test_records("lights", gold)
+    for f in ("Li", "wi", "pdf", "dist", "pdf_dir"):
+        assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
+    assert np.array_equal(out["is_delta"], gold["is_delta"])
+    cases = [(4, "img_scene%02d_i4_64_spp16.f64" % sid)] + ([(3, "img_scene18_i3_64_spp16.f64")] if sid == 18 else [])
+    for integ, img_name in cases:
+        name = "li_scene%02d_i%d.bin" % (sid, integ)
+        info = G.MANIFEST["files"][name]
+        grec = G.records(name, A.LI_DTYPE)
+        p = A.make_params(info["info"]["width"], info["info"]["height"], info["spp"], integrator=integ,
+                          seed=info["seed"])
+        o = ctx.test_records("li", grec, params=p)
+        # (the harness files a directional light's shadow rays, t_max = inf, under "closest")
+        same = (o["rng_exit"] == grec["rng_exit"]) & \
+               (o["n_closest"] + o["n_shadow"] == grec["n_closest"] + grec["n_shadow"])
+        assert same.mean() >= 0.995
+        assert np.all(_close(o["L"][same], grec["L"][same], 1e-9).all(axis=1))
+        img, iinfo = G.image(img_name)
+        for pipe in ((A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT) if integ == 4 else (A.PIPELINE_MEGAKERNEL,)):
+            q = A.make_params(iinfo["width"], iinfo["height"], iinfo["spp"], integrator=integ, seed=iinfo["seed"],
+                              pipeline=pipe)
+            assert G.rel_l2(ctx.render(q), img) <= REL_L2_BAR
+
+
 def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
     """host/rtr_cli.cpp: the C++ mirror of main.cpp + Renderer::render driving the same C ABI."""
     import os

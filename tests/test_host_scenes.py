@@ -50,8 +50,19 @@ def test_reference_scene_builders_drop_in(sid):
 
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_scenes is built only where the reference is")
+@pytest.mark.parametrize("sid", [15, 17, 18])
+def test_delta_light_scenes_drop_in(sid):
+    """Point / directional / spot light scenes of the reference, built against host/compat."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "s.rtrs")
+        r = subprocess.run([DROPIN, str(sid), "12345", out], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        assert r.returncode == 0, r.stdout
+        assert open(out, "rb").read() == G.scene(sid).to_bytes()
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_scenes is built only where the reference is")
 def test_unsupported_lights_are_rejected_not_ignored():
     with tempfile.TemporaryDirectory() as td:
-        r = subprocess.run([DROPIN, "15", "12345", os.path.join(td, "s.rtrs")], stdout=subprocess.PIPE,
+        r = subprocess.run([DROPIN, "19", "12345", os.path.join(td, "s.rtrs")], stdout=subprocess.PIPE,
                            stderr=subprocess.DEVNULL)
-        assert r.returncode == 3 and b"PointLight" in r.stdout
+        assert r.returncode == 3 and b"EnvironmentLight" in r.stdout
