@@ -23,9 +23,9 @@ HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 SCENE_SEED = 12345  # xorshift state before select_scene(): BVH axes, perlin tables, random geometry
 
 
-def run(*args):
+def run(*args, cwd=None):
     cmd = [HARNESS] + [str(a) for a in args]
-    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=cwd).stdout.decode()
     return cmd, json.loads(out.strip().splitlines()[-1]) if out.strip().startswith("{") else {}
 
 
@@ -96,6 +96,32 @@ def main():
         name = "img_scene%02d_i%d_%d_spp%d.f64" % (sid, integ, W, spp)
         cmd, info = run("render", sid, integ, W, spp, seed, SCENE_SEED, os.path.join(GOLD, name), 8)
         note(name, cmd, info, scene=sid, integrator=integ, width=W, height=info["height"], spp=spp, seed=seed)
+    # a REAL image texture.  None of the reference's assets ship, so a
+    # synthetic 96x48 picture is written as binary PPM under the name the scene asks for
+    # ("earthmap.jpg"; stb_image sniffs the format from the content) and the harness runs in that
+    # directory: scene 4 (earth(): one textured sphere) then loads it.
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        w, h = 96, 48
+        px = bytearray()
+        for j in range(h):
+            for i in range(w):
+                px += bytes(((i * 5 + j * 3) % 256, (i * i + 7 * j) % 256, (i ^ (3 * j)) % 256))
+        with open(os.path.join(td, "earthmap.jpg"), "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (w, h) + bytes(px))
+        name = "scene04.rtrs"
+        cmd, info = run("dump-scene", 4, SCENE_SEED, os.path.join(GOLD, name), cwd=td)
+        note(name, cmd, info, raw_sha256=sha(os.path.join(GOLD, name)), asset="synthetic 96x48 PPM as earthmap.jpg")
+        name = "hits_scene04.bin"
+        cmd, info = run("hits", 4, SCENE_SEED, 512, 781, os.path.join(GOLD, name), cwd=td)
+        note(name, cmd, info, scene=4)
+        name = "li_scene04_i1.bin"
+        cmd, info = run("li", 4, 1, 64, 16, 1, SCENE_SEED, 768, os.path.join(GOLD, name), cwd=td)
+        note(name, cmd, info, scene=4, integrator=1, width=64, spp=16, seed=1)
+        name = "img_scene04_i1_64_spp16.f64"
+        cmd, info = run("render", 4, 1, 64, 16, 1, SCENE_SEED, os.path.join(GOLD, name), 8, cwd=td)
+        note(name, cmd, info, scene=4, integrator=1, width=64, height=info["height"], spp=16, seed=1)
+
     # one mid-size image of the headline config's scene
     name = "img_scene21_i4_128_spp32.f64"
     cmd, info = run("render", 21, 4, 128, 32, 7, SCENE_SEED, os.path.join(GOLD, name), 8)

@@ -30,6 +30,30 @@ class RenderBuffer:
         """The bytes save_to_png writes (render_buffer.h:35-55): Y flipped, uchar(c * 255) truncation."""
         return (self.pixels[::-1] * 255.0).astype(np.uint8)
 
+    def save_to_png(self, filename):
+        """8-bit RGB PNG with the reference's pixel bytes (render_buffer.h:35-55).  The reference
+        encodes with stb_image_write; the zlib stream differs, the decoded pixels do not."""
+        import struct
+        import zlib
+        rgb = self.to_rgb8()
+        raw = b"".join(b"\x00" + rgb[j].tobytes() for j in range(self.height))
+
+        def chunk(tag, data):
+            return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+        png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", self.width, self.height, 8, 2, 0, 0, 0)) +
+               chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+        with open(filename, "wb") as f:
+            f.write(png)
+        return True
+
+
+def output_filename(scene_id, integrator_id, timestamp=None):
+    """``output/sceneNN_integratorK_<unixtime>.png`` (main.cpp:134-142)."""
+    import time
+    t = int(time.time()) if timestamp is None else int(timestamp)
+    return "output/scene%02d_integrator%d_%d.png" % (scene_id, integrator_id, t)
+
 
 def tiles_of_rank(width, height, rank, world):
     """Tile indices (reference dispatch order, renderer.h:61-62) owned by ``rank`` of ``world``:

@@ -309,6 +309,37 @@ def test_delta_lights(ctx, sid):
             assert G.rel_l2(ctx.render(q), img) <= REL_L2_BAR
 
 
+def test_image_texture(ctx):
+    """image_texture with real texels (scene 4 + synthetic picture): (u,v) from
+    acos/atan2 on the sphere, nearest-texel fetch.  The compiled path carries no (u,v), so this
+    scene runs the reference-order traversal."""
+    sc = _upload(ctx, 4)
+    assert G.rtr.native.validate_scene(sc)["needs_uv"]
+    gold = G.records("hits_scene04.bin", A.HIT_DTYPE)
+    out = ctx.test_records("hits", gold)
+    assert np.array_equal(out["hit"], gold["hit"])
+    h = gold["hit"] == 1
+    for f in ("t", "p", "n"):
+        assert np.array_equal(_bits(out[f][h]), _bits(gold[f][h])), f
+    for f in ("u", "v"):  # (atan2 + pi) / 2pi cancels near u = 0: absolute, not relative, agreement
+        assert np.all(np.abs(out[f][h] - gold[f][h]) <= 1e-14), f
+    name = "li_scene04_i1.bin"
+    info = G.MANIFEST["files"][name]
+    grec = G.records(name, A.LI_DTYPE)
+    p = A.make_params(info["info"]["width"], info["info"]["height"], info["spp"], integrator=1, seed=info["seed"])
+    o = ctx.test_records("li", grec, params=p)
+    same = o["rng_exit"] == grec["rng_exit"]
+    assert same.mean() >= 0.995
+    # an ulp of difference in (u,v) can select a neighbouring texel: allow a few samples to differ
+    ok = np.all(_close(o["L"][same], grec["L"][same], 1e-9), axis=1)
+    assert ok.mean() >= 0.99
+    img, iinfo = G.image("img_scene04_i1_64_spp16.f64")
+    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
+        q = A.make_params(iinfo["width"], iinfo["height"], iinfo["spp"], integrator=1, seed=iinfo["seed"],
+                          pipeline=pipe)
+        assert G.rel_l2(ctx.render(q), img) <= REL_L2_BAR
+
+
 def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
     """host/rtr_cli.cpp: the C++ mirror of main.cpp + Renderer::render driving the same C ABI."""
     import os

@@ -40,6 +40,26 @@ def test_render_buffer_store_matches_reference_output_stage():
     assert rb.to_rgb8()[0, 0].tolist() == [127, 255, 0]        # uchar(c * 255) truncation (render_buffer.h:44-49)
 
 
+def test_png_writer_and_filename(tmp_path):
+    """PNG with the reference's pixel bytes and its output file naming."""
+    import struct
+    import zlib
+    rb = rtr.RenderBuffer(5, 3)
+    rng = np.random.default_rng(0)
+    rb.store_linear(rng.random((3, 5, 3)) * 1.5)
+    path = str(tmp_path / "x.png")
+    assert rb.save_to_png(path)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    w, h, depth, ctype = struct.unpack(">IIBB", data[16:26])
+    assert (w, h, depth, ctype) == (5, 3, 8, 2)
+    idat_len = struct.unpack(">I", data[33:37])[0]
+    raw = zlib.decompress(data[41:41 + idat_len])
+    rows = np.frombuffer(raw, dtype=np.uint8).reshape(3, 1 + 5 * 3)[:, 1:].reshape(3, 5, 3)
+    assert np.array_equal(rows, rb.to_rgb8())
+    assert rtr.renderer.output_filename(7, 1, 1765799945) == "output/scene07_integrator1_1765799945.png"
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
