@@ -15,6 +15,9 @@
 #include <vector>
 
 struct CompiledScene {
+    std::vector<FSub> subs;
+    std::vector<rtr_node> dev_nodes; /* node array the device walks: subtrees replaced by RT_NODE_COMPILED */
+    int n_compiled_subtrees = 0;
     std::vector<FInst> inst;
     std::vector<FXf> xf;
     std::vector<FRef> ref;
@@ -51,17 +54,21 @@ struct PendingRef {
     int node;
     std::vector<int> wrappers; /* outermost first, as met on the way down */
     Box local;
+    int order; /* position of the primitive's LAST visit in the reference's walk (tie-breaks equal t) */
 };
 
 struct Builder {
     const rtr_scene_desc* s;
-    CompiledScene out;
+    CompiledScene& out;
+    int inst_base = 0;
+    explicit Builder(CompiledScene& o) : out(o) {}
     double t_lo, t_hi; /* ray times the camera and the shadow rays can carry */
     std::vector<int> chain;    /* translate / rotate_y node indices, outermost first */
     std::vector<int> wrappers; /* the same plus flip_face */
     std::map<std::vector<uint64_t>, int> inst_of_chain;
     std::vector<std::vector<PendingRef>> pending; /* per instance */
-    std::set<std::pair<int, std::vector<uint64_t>>> seen;
+    std::map<std::pair<int, std::vector<uint64_t>>, std::pair<int, int>> seen; /* -> (instance, slot) */
+    int visit_counter = 0;
     bool too_complex = false;
 
     static uint64_t bits(double v) {
@@ -142,13 +149,19 @@ struct Builder {
             break;
         case RTR_NODE_MEDIUM: too_complex = true; break;
         default: {
-            if (!seen.insert({ix, full_key()}).second) break; /* same primitive, same frame: one test is enough */
+            const int order = visit_counter++;
+            auto sk = std::make_pair(ix, full_key());
+            auto seen_it = seen.find(sk);
+            if (seen_it != seen.end()) { /* same primitive, same frame: one test is enough; the later visit wins ties */
+                pending[seen_it->second.first][seen_it->second.second].order = order;
+                break;
+            }
             const std::vector<uint64_t> key = chain_key();
             auto it = inst_of_chain.find(key);
             int ii;
             if (it == inst_of_chain.end()) {
                 ii = (int)out.inst.size();
-                if (ii >= kMaxInstances) {
+                if (ii - inst_base >= kMaxInstances) {
                     too_complex = true;
                     break;
                 }
@@ -169,7 +182,8 @@ struct Builder {
             } else {
                 ii = it->second;
             }
-            pending[ii].push_back(PendingRef{ix, wrappers, prim_box(n)});
+            seen[sk] = {ii - inst_base, (int)pending[ii - inst_base].size()};
+            pending[ii - inst_base].push_back(PendingRef{ix, wrappers, prim_box(n), order});
         }
         }
     }
@@ -222,16 +236,23 @@ struct Builder {
         return me;
     }
 
-    bool run() {
+    /* compile the subtree under `root`; returns the sub-scene index or -1 (media / too fragmented) */
+    int run(int root) {
         /* camera rays carry a time in [time0, time1], shadow rays time 0 (mis_path_integrator.h:210) */
         t_lo = std::min(0.0, std::min(s->camera.time0, s->camera.time1));
         t_hi = std::max(0.0, std::max(s->camera.time0, s->camera.time1));
-        walk(s->root);
-        if (too_complex || out.inst.empty()) return false;
+        const size_t mark[6] = {out.inst.size(), out.xf.size(), out.ref.size(), out.exits.size(), out.bvh.size(), 0};
+        inst_base = (int)out.inst.size();
+        walk(root);
+        if (too_complex || (int)out.inst.size() == inst_base) { /* undo */
+            out.inst.resize(mark[0]), out.xf.resize(mark[1]), out.ref.resize(mark[2]), out.exits.resize(mark[3]);
+            out.bvh.resize(mark[4]);
+            return -1;
+        }
         int stack = 1;
-        for (size_t ii = 0; ii < out.inst.size(); ++ii) {
+        for (size_t ii = inst_base; ii < out.inst.size(); ++ii) {
             FInst& I = out.inst[ii];
-            std::vector<PendingRef>& refs = pending[ii];
+            std::vector<PendingRef>& refs = pending[ii - inst_base];
             I.ref_first = (int)out.ref.size();
             I.n_ref = (int)refs.size();
             const int first_bvh = (int)out.bvh.size();
@@ -248,6 +269,7 @@ struct Builder {
                 fr.node = r.node;
                 fr.exit_first = (int)out.exits.size();
                 fr.n_exit = (int)r.wrappers.size();
+                fr.pad = r.order;
                 for (auto it = r.wrappers.rbegin(); it != r.wrappers.rend(); ++it) out.exits.push_back(*it);
                 out.ref.push_back(fr);
                 local.grow(r.local);
@@ -262,20 +284,114 @@ struct Builder {
             world.pad();
             for (int c = 0; c < 3; ++c) I.bmin[c] = world.lo[c], I.bmax[c] = world.hi[c];
         }
-        out.stack_words = stack;
-        out.ok = true;
-        return true;
+        out.stack_words = std::max(out.stack_words, stack);
+        FSub sub{};
+        sub.inst_first = inst_base;
+        sub.n_inst = (int)out.inst.size() - inst_base;
+        out.subs.push_back(sub);
+        return (int)out.subs.size() - 1;
+    }
+};
+
+/* per node: primitives below it and whether a constant_medium is below it (DAG-aware) */
+struct SubtreeFacts {
+    std::vector<int> prims;
+    std::vector<char> media, done;
+    const rtr_scene_desc* s;
+    void visit(int ix) {
+        if (done[ix]) return;
+        done[ix] = 1;
+        const rtr_node& n = s->nodes[ix];
+        int p = 0;
+        char m = 0;
+        auto child = [&](int c) {
+            visit(c);
+            p += prims[c];
+            m |= media[c];
+        };
+        switch (n.type) {
+        case RTR_NODE_BVH:
+            child(n.a);
+            if (n.b != n.a) child(n.b);
+            break;
+        case RTR_NODE_LIST:
+            for (int k = 0; k < n.b; ++k) child(s->list_children[n.a + k]);
+            break;
+        case RTR_NODE_TRANSLATE:
+        case RTR_NODE_ROTATE_Y:
+        case RTR_NODE_FLIP_FACE: child(n.a); break;
+        case RTR_NODE_MEDIUM:
+            child(n.a);
+            m = 1;
+            break;
+        default: p = 1;
+        }
+        prims[ix] = p;
+        media[ix] = m;
     }
 };
 
 } // namespace rtc
 
-/* `scene` must have passed validation.  Returns a compiled scene with ok = false when the
- * scene has media or is too fragmented (then the reference-order traversal is used). */
+/* `scene` must have passed validation.
+ *  - no media: sub-scene 0 = the whole scene (ok = true), device nodes = the scene's nodes;
+ *  - media: ok = false (the reference-order walk stays in charge), but every media-free subtree
+ *    with at least kMinCompiled primitives met on the way down from the root is compiled and its
+ *    node replaced by RT_NODE_COMPILED in the device copy of the node array. */
 inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) {
-    if (has_media) return CompiledScene{};
-    rtc::Builder b;
-    b.s = scene;
-    if (!b.run()) return CompiledScene{};
-    return std::move(b.out);
+    CompiledScene cs;
+    cs.dev_nodes.assign(scene->nodes, scene->nodes + scene->n_nodes);
+    if (!has_media) {
+        rtc::Builder b(cs);
+        b.s = scene;
+        cs.ok = b.run(scene->root) == 0;
+        if (!cs.ok) {
+            cs.subs.clear();
+            cs.stack_words = 1;
+        }
+        return cs;
+    }
+    constexpr int kMinCompiled = 8;
+    rtc::SubtreeFacts facts;
+    facts.s = scene;
+    facts.prims.assign(scene->n_nodes, 0);
+    facts.media.assign(scene->n_nodes, 0);
+    facts.done.assign(scene->n_nodes, 0);
+    facts.visit(scene->root);
+    std::vector<char> seen(scene->n_nodes, 0);
+    std::vector<int> todo{scene->root};
+    while (!todo.empty()) {
+        const int ix = todo.back();
+        todo.pop_back();
+        if (seen[ix]) continue;
+        seen[ix] = 1;
+        const rtr_node& n = scene->nodes[ix];
+        if (!facts.media[ix]) {
+            if (facts.prims[ix] >= kMinCompiled) {
+                rtc::Builder b(cs);
+                b.s = scene;
+                const int sub = b.run(ix);
+                if (sub >= 0) {
+                    rtr_node c{};
+                    c.type = RT_NODE_COMPILED;
+                    c.a = sub;
+                    cs.dev_nodes[ix] = c;
+                    ++cs.n_compiled_subtrees;
+                }
+            }
+            continue; /* small media-free subtrees stay interpreted */
+        }
+        switch (n.type) {
+        case RTR_NODE_BVH: todo.push_back(n.a), todo.push_back(n.b); break;
+        case RTR_NODE_LIST:
+            for (int k = 0; k < n.b; ++k) todo.push_back(scene->list_children[n.a + k]);
+            break;
+        case RTR_NODE_TRANSLATE:
+        case RTR_NODE_ROTATE_Y:
+        case RTR_NODE_FLIP_FACE: todo.push_back(n.a); break;
+        default: break; /* a medium: its boundary is cast t-only by the walk */
+        }
+    }
+    cs.ok = false;
+    return cs;
 }

@@ -171,7 +171,8 @@ struct DScene {
     const rtr_node* fprim; /* copy of the primitive's node record per reference (one load hop less) */
     const int32_t* fexit;
     const struct FBvh* fbvh;
-    int32_t n_finst;
+    const struct FSub* fsub; /* compiled sub-scenes: [0] = whole scene when it has no media */
+    int32_t n_finst;         /* instances of sub-scene 0 (0 = none) */
     int32_t fast_pad;
 };
 
@@ -203,12 +204,21 @@ struct FRef {
     int32_t node;       /* primitive node index */
     int32_t exit_first; /* into fexit: wrapper node indices, innermost first */
     int32_t n_exit;
-    int32_t pad;
+    int32_t pad;        /* host side: visiting order (copied into fprim[].reserved) */
 };
 struct FBvh {
     double bmin[3], bmax[3];
     int32_t left, right; /* right < 0: leaf holding references [left, left - right) */
 };
+/* A compiled sub-scene = a range of instances.  Scenes WITH media keep the reference-order walk
+ * for the (small) part of the graph the media live in, and every large media-free subtree under
+ * it is compiled on its own: the walk meets it as one node of type RT_NODE_COMPILED at the place
+ * the reference would enter that subtree, with the same t_max, so RNG draws and results of the
+ * media around it are unchanged while the bulk of the geometry is traversed order-free. */
+struct FSub {
+    int32_t inst_first, n_inst;
+};
+#define RT_NODE_COMPILED 11 /* device-only node type: a = sub-scene index */
 
 struct Hit { /* geometry/hittable.h:10-23 */
     V3 p, n;
@@ -379,6 +389,14 @@ RT_DEV void wrapper_enter(int type, const double* f, V3& o, V3& d) {
     }
 }
 
+/* defined below (order-free traversal of compiled sub-scenes) */
+template <bool ANY>
+__device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
+                                           Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
+                                           const Stack st, const int sp0);
+template <bool UV>
+RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec);
+
 /*
  * Closest hit of the hittable graph under `root`: an iterative restatement of the
  * reference's recursive virtual hit() calls that visits objects in the same order
@@ -421,7 +439,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
                 st.put(sp++, n.b);
                 st.put(sp++, n.a);
             }
-        } else if (type >= RTR_NODE_XY_RECT) {
+        } else if (type >= RTR_NODE_XY_RECT && type <= RTR_NODE_YZ_RECT) {
             Real t, a, b;
             if (rect_hit_t(n, type, o, d, tmin, tmax, t, a, b)) {
                 tmax = t;
@@ -459,6 +477,18 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
             st.put(sp++, hits);
             st.put(sp++, -(e + 1));
             st.put(sp++, n.a);
+        } else if (MEDIA && type == RT_NODE_COMPILED) { /* a media-free subtree, compiled (see FSub) */
+            const FSub sub = ld_const(sc.fsub, n.a);
+            int ref, inst;
+            if (trace_fast<false>(sc, sub.inst_first, sub.n_inst, o, d, time, tmin, tmax, ref, inst, st, sp)) {
+                ++hits;
+                if (FULL) {
+                    if (sc.needs_uv)
+                        fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
+                    else
+                        fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec);
+                }
+            }
         } else if (MEDIA && type == RTR_NODE_MEDIUM) { /* geometry/constant_medium.h:55-104 */
             Hit dummy;
             Real t1 = RT_INF;
@@ -507,7 +537,10 @@ RT_DEV bool box_enter(const double* bmin, const double* bmax, V3 o, V3 inv, Real
     return lo <= hi; /* NaNs (0 * inf) drop out of fmin/fmax, which keeps the test conservative */
 }
 
-/* one reference of an instance against the ray in the instance frame */
+/* One reference of an instance against the ray in the instance frame.  (Exact ties in t, e.g. the
+ * coplanar side faces of adjacent boxes in scene 9, are won by whichever primitive is tested
+ * last; in the reference that is decided by 1-ulp noise of its BVH box tests, so neither order
+ * can be called "the" reference behaviour.  Such faces share material and normal there.) */
 RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
     const rtr_node n = ld_const(sc.fprim, ref);
     const int type = n.type;
@@ -524,16 +557,17 @@ RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real 
 /* Closest hit (ANY = false) or first hit found (ANY = true: shadow rays only need existence).
  * Returns the reference and instance of the hit; `tmax` returns its t. */
 template <bool ANY>
-__device__ __forceinline__ bool trace_fast(const DScene& sc, V3 o, V3 d, Real time, Real tmin, Real& tmax,
-                                           int& hit_ref, int& hit_inst, const Stack st) {
+__device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
+                                           Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
+                                           const Stack st, const int sp0) {
     /* with a handful of instances some lane of the wave enters every one of them, so the boxes
      * would prune nothing at wave level: skip them (and the three divisions of 1/d) */
-    const bool use_boxes = sc.n_finst > RT_FAST_NO_BOX_MAX;
+    const bool use_boxes = n_inst > RT_FAST_NO_BOX_MAX;
     V3 inv = mk(0, 0, 0);
     if (use_boxes) inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     hit_ref = -1;
     hit_inst = -1;
-    for (int ii = 0; ii < sc.n_finst; ++ii) {
+    for (int ii = inst_first; ii < inst_first + n_inst; ++ii) {
         const FInst I = ld_const(sc.finst, ii);
         V3 lo = o, ld = d, linv = inv;
         const int n_xf = I.n_xf;
@@ -560,9 +594,9 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, V3 o, V3 d, Real ti
                 }
             }
         } else {
-            int sp = 0;
+            int sp = sp0;
             st.put(sp++, I.bvh_root);
-            while (sp > 0) {
+            while (sp > sp0) {
                 const FBvh& b = sc.fbvh[st.get(--sp)];
                 if (b.right < 0) {
                     for (int r = b.left; r < b.left - b.right; ++r) {
@@ -655,7 +689,7 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
     Real tmax = RT_INF;
     if (TRAV == RT_TRAV_FAST) {
         int ref, inst;
-        if (!trace_fast<false>(sc, o, d, time, 0.001, tmax, ref, inst, st)) return false;
+        if (!trace_fast<false>(sc, 0, sc.n_finst, o, d, time, 0.001, tmax, ref, inst, st, 0)) return false;
         fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec); /* scenes whose textures read (u,v) use the reference-order traversal */
         return true;
     }
@@ -665,7 +699,7 @@ template <int TRAV>
 __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real tmax, uint32_t& rng, const Stack st) {
     if (TRAV == RT_TRAV_FAST) {
         int ref, inst;
-        return trace_fast<true>(sc, o, d, 0.0, 0.001, tmax, ref, inst, st);
+        return trace_fast<true>(sc, 0, sc.n_finst, o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
     }
     Hit dummy;
     return traverse<false, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, 0.0, 0.001, tmax, dummy, rng, st, 0);

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hi
     bool h;
     if (TRAV == RT_TRAV_FAST) {
         int ref, inst;
-        h = trace_fast<false>(sc, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st);
+        h = trace_fast<false>(sc, 0, sc.n_finst, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st, 0);
         if (h) fast_finish<true>(sc, ld3(r.o), ld3(r.d), r.time, tmax, ref, inst, rec);
     } else {
         h = traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, rec, rng, st, 0);

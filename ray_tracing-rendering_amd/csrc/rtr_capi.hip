@@ -37,8 +37,9 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub;
     int fast_stack_words = 1;
+    int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool force_exact = false;
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures */
     int n_material_types = 0;
@@ -304,7 +305,7 @@ int pick_trav(const rtr_context* c, int flags) {
     return RT_TRAV_FAST;
 }
 size_t stack_bytes(const rtr_context* c, int trav) {
-    const int words = trav == RT_TRAV_FAST ? c->fast_stack_words : c->info.stack_words;
+    const int words = trav == RT_TRAV_FAST ? c->fast_stack_words : c->info.stack_words + c->walk_extra_words;
     return (size_t)words * RTR_BLOCK * sizeof(int);
 }
 
@@ -412,6 +413,7 @@ int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* 
         info->fast_instances = (int32_t)cs.inst.size();
         info->fast_refs = (int32_t)cs.ref.size();
         info->fast_stack_words = cs.stack_words;
+        info->compiled_subtrees = cs.n_compiled_subtrees;
     }
     return rc;
 }
@@ -461,7 +463,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -487,12 +489,13 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     rtr_scene_info info{};
     int rc = v.run(&info);
     if (rc) return fail(c, rc, "scene rejected: " + v.msg);
-    if ((size_t)info.stack_words * RTR_BLOCK * sizeof(int) > 160 * 1024)
+    if ((size_t)(info.stack_words + 64) * RTR_BLOCK * sizeof(int) > 160 * 1024)
         return fail(c, RTR_ERR_UNSUPPORTED, "scene needs a deeper traversal stack than 160 KiB of LDS holds");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
-    if ((rc = upload(c, c->b_nodes, s->nodes, sizeof(rtr_node) * s->n_nodes))) return rc;
+    CompiledScene cs = compile_scene(s, info.has_media != 0);
+    if ((rc = upload(c, c->b_nodes, cs.dev_nodes.data(), sizeof(rtr_node) * cs.dev_nodes.size()))) return rc;
     if ((rc = upload(c, c->b_kids, s->list_children, sizeof(int32_t) * s->n_list_children))) return rc;
     if ((rc = upload(c, c->b_mats, s->materials, sizeof(rtr_material) * s->n_materials))) return rc;
     if ((rc = upload(c, c->b_tex, s->textures, sizeof(rtr_texture) * s->n_textures))) return rc;
@@ -500,22 +503,27 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     if ((rc = upload(c, c->b_images, s->images, sizeof(rtr_image) * s->n_images))) return rc;
     if ((rc = upload(c, c->b_imgbytes, s->image_bytes, s->n_image_bytes))) return rc;
     if ((rc = upload(c, c->b_lights, s->lights, sizeof(rtr_light) * s->n_lights))) return rc;
-    CompiledScene cs = compile_scene(s, info.has_media != 0);
     info.fast_ok = cs.ok;
     info.fast_instances = (int32_t)cs.inst.size();
     info.fast_refs = (int32_t)cs.ref.size();
     info.fast_stack_words = cs.stack_words;
+    info.compiled_subtrees = cs.n_compiled_subtrees;
     if ((rc = upload(c, c->b_finst, cs.inst.data(), sizeof(FInst) * cs.inst.size()))) return rc;
     if ((rc = upload(c, c->b_fxf, cs.xf.data(), sizeof(FXf) * cs.xf.size()))) return rc;
     if ((rc = upload(c, c->b_fref, cs.ref.data(), sizeof(FRef) * cs.ref.size()))) return rc;
     if ((rc = upload(c, c->b_fexit, cs.exits.data(), sizeof(int32_t) * cs.exits.size()))) return rc;
     if ((rc = upload(c, c->b_fbvh, cs.bvh.data(), sizeof(FBvh) * cs.bvh.size()))) return rc;
+    if ((rc = upload(c, c->b_fsub, cs.subs.data(), sizeof(FSub) * cs.subs.size()))) return rc;
     {
         std::vector<rtr_node> prims(cs.ref.size());
-        for (size_t k = 0; k < cs.ref.size(); ++k) prims[k] = s->nodes[cs.ref[k].node];
+        for (size_t k = 0; k < cs.ref.size(); ++k) {
+            prims[k] = s->nodes[cs.ref[k].node]; /* original records */
+            prims[k].reserved = cs.ref[k].pad;      /* visiting order of the reference's walk */
+        }
         if ((rc = upload(c, c->b_fprim, prims.data(), sizeof(rtr_node) * prims.size()))) return rc;
     }
     c->fast_stack_words = cs.stack_words;
+    c->walk_extra_words = cs.n_compiled_subtrees ? cs.stack_words : 0;
     DScene& d = c->ds;
     d.finst = static_cast<const FInst*>(c->b_finst.p);
     d.fxf = static_cast<const FXf*>(c->b_fxf.p);
@@ -523,7 +531,8 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fprim = static_cast<const rtr_node*>(c->b_fprim.p);
     d.fexit = static_cast<const int32_t*>(c->b_fexit.p);
     d.fbvh = static_cast<const FBvh*>(c->b_fbvh.p);
-    d.n_finst = cs.ok ? (int32_t)cs.inst.size() : 0;
+    d.fsub = static_cast<const FSub*>(c->b_fsub.p);
+    d.n_finst = cs.ok ? cs.subs[0].n_inst : 0;
     d.fast_pad = 0;
     d.nodes = static_cast<const rtr_node*>(c->b_nodes.p);
     d.list_children = static_cast<const int32_t*>(c->b_kids.p);

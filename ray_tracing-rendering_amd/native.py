@@ -27,7 +27,8 @@ EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "
 class SceneInfoC(C.Structure):
     _fields_ = [("stack_words", C.c_int32), ("has_media", C.c_int32), ("needs_uv", C.c_int32),
                 ("graph_depth", C.c_int32), ("fast_ok", C.c_int32), ("fast_instances", C.c_int32),
-                ("fast_refs", C.c_int32), ("fast_stack_words", C.c_int32)]
+                ("fast_refs", C.c_int32), ("fast_stack_words", C.c_int32), ("compiled_subtrees", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class RtrError(RuntimeError):
@@ -92,7 +93,8 @@ def validate_scene(scene):
         raise RtrError(rc, msg.value.decode())
     return {"stack_words": info.stack_words, "has_media": bool(info.has_media), "needs_uv": bool(info.needs_uv),
             "graph_depth": info.graph_depth, "fast_ok": bool(info.fast_ok), "fast_instances": info.fast_instances,
-            "fast_refs": info.fast_refs, "fast_stack_words": info.fast_stack_words}
+            "fast_refs": info.fast_refs, "fast_stack_words": info.fast_stack_words,
+            "compiled_subtrees": info.compiled_subtrees}
 
 
 class Context:

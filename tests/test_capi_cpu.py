@@ -36,7 +36,7 @@ def test_sample_seed_matches_oracle():
 def test_struct_sizes_match_headers():
     assert C.sizeof(A.SceneDescC) == 4 * 10 + 8 + 8 * 8 + 192 + 24
     assert C.sizeof(A.RenderParamsC) == 16 * 4
-    assert C.sizeof(rtr.native.SceneInfoC) == 8 * 4
+    assert C.sizeof(rtr.native.SceneInfoC) == 12 * 4
     assert C.sizeof(A.CameraC) == 192
 
 
@@ -51,6 +51,8 @@ def test_validate_golden_scenes(sid, words, media):
         assert (info["fast_instances"], info["fast_refs"], info["fast_stack_words"]) == (3, 18, 1)
     if sid == 23:
         assert (info["fast_instances"], info["fast_refs"]) == (1, 6)
+    if media:  # the box field, and the BVH branch holding the sphere cloud + 2 spheres, are compiled
+        assert info["compiled_subtrees"] == 2 and info["fast_refs"] == 2400 + 1000 + 2
 
 
 def _mutated(sid, fn):

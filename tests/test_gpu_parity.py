@@ -64,9 +64,18 @@ def test_unit_closest_hit(ctx, sid):
     for f in ("t", "p", "n"):
         ok = _close(out[f][both], gold[f][both], 1e-12)
         assert ok.mean() >= 0.999, f
-    uv = both & ~np.isnan(gold["u"])
+    # (u,v) only where the final primitive writes them: moving_sphere and constant_medium leave
+    # whatever an earlier, farther hit of the same walk stored (hittable.h:10-17 is never reset),
+    # which depends on visiting order inside compiled subtrees
+    sc = G.scene(sid)
+    no_uv_mats = set(np.flatnonzero(sc.materials["type"] == A.MAT_ISOTROPIC).tolist())
+    no_uv_mats |= set(sc.nodes["a"][sc.nodes["type"] == A.NODE_MOVING_SPHERE].tolist())
+    uv = both & ~np.isnan(gold["u"]) & ~np.isin(gold["material"], sorted(no_uv_mats))
+    # a ray through the coplanar side faces of two adjacent ground boxes ties exactly in t; the
+    # winner (in the reference: 1-ulp noise of its BVH box tests) only changes the face-relative
+    # (u,v): allow a few such records
     for f in ("u", "v"):  # acos / atan2 from OCML
-        assert _close(out[f][uv], gold[f][uv], 1e-12).mean() >= 0.999, f
+        assert _close(out[f][uv], gold[f][uv], 1e-12).mean() >= 0.995, f
     assert np.array_equal(out["front_face"][both], gold["front_face"][both])
 
 
