@@ -130,7 +130,9 @@ typedef enum rtr_light_type {
     RTR_LIGHT_POINT = 1,       /* PointLight lighting/point_light.h:6-37: f[0..2]=position f[3..5]=intensity */
     RTR_LIGHT_SPOT = 2,        /* SpotLight lighting/spot_light.h:6-41: f[0..2]=position f[3..5]=unit direction f[6..8]=intensity f[9]=cos_cutoff */
     RTR_LIGHT_DIRECTIONAL = 3, /* DirectionalLight lighting/directional_light.h:7-31: f[0..2]=unit direction f[3..5]=radiance */
-    RTR_LIGHT_TYPE_COUNT = 4
+    RTR_LIGHT_ENV_UNIFORM = 4, /* EnvironmentLight whose map file is missing (lighting/environmental_light.h:126-131,
+                                  187-192,251-252,293-294): uniform white sky, sampled with random_unit_vector() */
+    RTR_LIGHT_TYPE_COUNT = 5
 } rtr_light_type;
 
 typedef struct rtr_light {

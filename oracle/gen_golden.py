@@ -50,7 +50,7 @@ def main():
     note("rng.bin", cmd, info)
 
     # flattened scenes (walked from the reference's own object graph)
-    for sid in (7, 21, 23, 9, 22, 15, 17, 18):
+    for sid in (7, 21, 23, 9, 22, 15, 17, 18, 19):
         name = "scene%02d.rtrs" % sid
         path = os.path.join(GOLD, name)
         cmd, info = run("dump-scene", sid, SCENE_SEED, path)
@@ -76,7 +76,7 @@ def main():
         name = "materials_scene%02d.bin" % sid
         cmd, info = run("materials", sid, SCENE_SEED, n, 4242 + sid, os.path.join(GOLD, name))
         note(name, cmd, info, scene=sid)
-    for sid, n in ((21, 256), (23, 256), (15, 128), (17, 128), (18, 128)):
+    for sid, n in ((21, 256), (23, 256), (15, 128), (17, 128), (18, 128), (19, 128)):
         name = "lights_scene%02d.bin" % sid
         cmd, info = run("lights", sid, SCENE_SEED, n, 99 + sid, os.path.join(GOLD, name))
         note(name, cmd, info, scene=sid)
@@ -87,7 +87,9 @@ def main():
              # integrators 0 (plain path), 2 (BSDF-only), 3 (NEE without MIS)
              (7, 0, 48, 8, 1), (23, 2, 64, 16, 1), (21, 3, 64, 16, 1), (23, 3, 64, 16, 1),
              # delta lights (point 15, directional 17, spot 18)
-             (15, 4, 64, 16, 1), (17, 4, 64, 16, 1), (18, 4, 64, 16, 1), (18, 3, 64, 16, 1)]
+             (15, 4, 64, 16, 1), (17, 4, 64, 16, 1), (18, 4, 64, 16, 1), (18, 3, 64, 16, 1),
+             # the map-less EnvironmentLight (uniform white sky): scene 19
+             (19, 4, 64, 16, 1), (19, 3, 64, 16, 1)]
     for sid, integ, W, spp, seed in cases:
         name = "li_scene%02d_i%d.bin" % (sid, integ)
         n_li = 2048 if (sid, integ) in ((7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4)) else 768

@@ -279,6 +279,9 @@ struct Flattener {
             r.type = RTR_LIGHT_DIRECTIONAL;
             put3(r.f, dl->direction);
             put3(r.f + 3, dl->L);
+        } else if (auto el = dynamic_cast<const EnvironmentLight*>(l)) {
+            if (el->width != 0 || el->height != 0) die("EnvironmentLight with a loaded map is not flattened yet");
+            r.type = RTR_LIGHT_ENV_UNIFORM;
         } else {
             die("unsupported light class in reference scene");
         }
@@ -612,6 +615,7 @@ static int cmd_lights(int scene_id, uint32_t scene_seed, int n_per, uint64_t gen
             vec3 p(lo.x() + (hi.x() - lo.x()) * U01(g), lo.y() + (hi.y() - lo.y()) * U01(g),
                    lo.z() + (hi.z() - lo.z()) * U01(g));
             vec2 u(U01(g), U01(g));
+            set_rng(0x2545F491u); /* EnvironmentLight::sample draws from the global generator */
             LightSample s = L->sample(p, u);
             /* pdf() query: half the time towards the sampled point, else random */
             vec3 dir = (k % 2 == 0) ? s.wi * (0.5 + U01(g)) : gen_unit(g);

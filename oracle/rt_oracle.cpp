@@ -657,8 +657,16 @@ struct LightSample {
     double pdf, dist;
     bool is_delta;
 };
-LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy) {
+LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy, Rng& g) {
     LightSample s;
+    if (l.type == RTR_LIGHT_ENV_UNIFORM) { /* environmental_light.h:182-192: no map loaded */
+        s.dist = kInf;
+        s.is_delta = false;
+        s.wi = random_unit_vector(g);
+        s.pdf = 1.0 / (4.0 * kPi);
+        s.Li = mk(1, 1, 1);
+        return s;
+    }
     if (l.type == RTR_LIGHT_POINT) { /* point_light.h:12-22 */
         V3 direction = sub(ld(l.f), p);
         double dist_squared = len2(direction);
@@ -711,6 +719,7 @@ LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy) {
     return s;
 }
 double light_pdf(const rtr_light& l, V3 origin, V3 direction) { /* quad_light.h:50-77 */
+    if (l.type == RTR_LIGHT_ENV_UNIFORM) return 1.0 / (4.0 * kPi); /* environmental_light.h:293-294 */
     if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf base (light.h:26-28): delta lights */
     V3 Q = ld(l.f), U = ld(l.f + 3), Vv = ld(l.f + 6), normal = ld(l.f + 12);
     double area = l.f[15];
@@ -766,6 +775,19 @@ double compute_light_pdf(const Scene& sc, const Ray& current_ray) { /* :173-188 
     return total_pdf;
 }
 
+/* radiance of the infinite lights seen by a ray that left the scene (environmental_light.h:226-229:
+ * Le = (1,1,1) without a map); `found` = some light is infinite */
+V3 env_radiance(const Scene& sc, bool& found) {
+    V3 env = mk(0, 0, 0);
+    found = false;
+    for (int k = 0; k < sc.d->n_lights; ++k)
+        if (sc.d->lights[k].type == RTR_LIGHT_ENV_UNIFORM) {
+            env = add(env, mk(1, 1, 1));
+            found = true;
+        }
+    return env;
+}
+
 V3 sample_lights_mis(const Scene& sc, const Rec& rec, V3 wo, Rng& g, Counters& cnt) { /* :191-234 */
     const int n_lights = sc.d->n_lights;
     if (n_lights == 0) return mk(0, 0, 0);
@@ -776,7 +798,7 @@ V3 sample_lights_mis(const Scene& sc, const Rec& rec, V3 wo, Rng& g, Counters& c
     /* vec2 u(random_double(), random_double()): u.y takes the first draw (g++ order) */
     double uy = g.next();
     double ux = g.next();
-    LightSample ls = light_sample(light, rec.p, ux, uy);
+    LightSample ls = light_sample(light, rec.p, ux, uy, g);
     if (ls.pdf > 0 && len2(ls.Li) > 0) {
         Ray shadow_ray = make_ray(rec.p, ls.wi, 0);
         Rec shadow_rec;
@@ -810,9 +832,17 @@ V3 li_mis(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g, Co
         Rec rec;
         rec.u = rec.v = 0;
         ++cnt.closest;
-        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) {
-            /* no infinite light type is flattened, so found_env is false (:41-50) */
-            L = add(L, mul(throughput, background));
+        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) { /* :37-67 */
+            bool found_env;
+            V3 env_L = env_radiance(sc, found_env);
+            if (!found_env) {
+                L = add(L, mul(throughput, background));
+            } else if (depth == 0 || specular_bounce) {
+                L = add(L, mul(throughput, env_L));
+            } else {
+                double mis_weight = power_heuristic(prev_bsdf_pdf, compute_light_pdf(sc, current_ray));
+                L = add(L, scl(mis_weight, mul(throughput, env_L)));
+            }
             break;
         }
         V3 wo = neg(unit(current_ray.d));
@@ -958,7 +988,7 @@ V3 sample_lights_direct(const Scene& sc, const Rec& rec, V3 wo, Rng& g, Counters
     double light_pdf_sel = 1.0 / n_lights;
     double uy = g.next();
     double ux = g.next();
-    LightSample ls = light_sample(light, rec.p, ux, uy);
+    LightSample ls = light_sample(light, rec.p, ux, uy, g);
     if (ls.pdf > 0 && len2(ls.Li) > 0) {
         Ray shadow_ray = make_ray(rec.p, ls.wi, 0);
         Rec shadow_rec;
@@ -991,8 +1021,14 @@ V3 li_direct(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g,
         Rec rec;
         rec.u = rec.v = 0;
         ++cnt.closest;
-        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) {
-            L = add(L, mul(throughput, background));
+        if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) { /* :41-54 */
+            bool found_env = false;
+            for (int k = 0; k < sc.d->n_lights; ++k)
+                if (sc.d->lights[k].type == RTR_LIGHT_ENV_UNIFORM) {
+                    L = add(L, mul(throughput, mk(1, 1, 1)));
+                    found_env = true;
+                }
+            if (!found_env) L = add(L, mul(throughput, background));
             break;
         }
         V3 wo = neg(unit(current_ray.d));
@@ -1185,7 +1221,8 @@ int rto_lights(const rtr_scene_desc* scene, rtr_light_record* recs, int64_t n) {
         rtr_light_record& o = recs[k];
         if (o.light < 0 || o.light >= scene->n_lights) return RTR_ERR_INVALID;
         const rtr_light& l = scene->lights[o.light];
-        LightSample s = light_sample(l, ld(o.p), o.u[0], o.u[1]);
+        Rng g{0x2545F491u}; /* the uniform environment light draws its direction itself */
+        LightSample s = light_sample(l, ld(o.p), o.u[0], o.u[1], g);
         o.Li[0] = s.Li.x, o.Li[1] = s.Li.y, o.Li[2] = s.Li.z;
         o.wi[0] = s.wi.x, o.wi[1] = s.wi.y, o.wi[2] = s.wi.z;
         o.pdf = s.pdf, o.dist = s.dist, o.is_delta = s.is_delta, o.pad2 = 0;

@@ -1057,9 +1057,17 @@ struct LightSample {
     Real pdf, dist;
     bool is_delta;
 };
-RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy) {
+RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy, uint32_t& rng) {
     LightSample s;
     const int type = l.type;
+    if (type == RTR_LIGHT_ENV_UNIFORM) { /* lighting/environmental_light.h:182-192 (no map loaded) */
+        s.dist = RT_INF;
+        s.is_delta = false;
+        s.wi = random_unit_vector(rng); /* drawn from the same generator, after u */
+        s.pdf = 1.0 / (4.0 * RT_PI);
+        s.Li = mk(1, 1, 1);
+        return s;
+    }
     if (type != RTR_LIGHT_QUAD) {
         s.is_delta = true;
         s.pdf = 1.0;
@@ -1100,6 +1108,7 @@ RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy) {
     return s;
 }
 RT_DEV Real light_pdf(const rtr_light& l, V3 origin, V3 direction) {
+    if (l.type == RTR_LIGHT_ENV_UNIFORM) return 1.0 / (4.0 * RT_PI); /* environmental_light.h:293-294 */
     if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf (light.h:26-28): delta lights */
     V3 Q = ld3(l.f), U = ld3(l.f + 3), Vv = ld3(l.f + 6), normal = ld3(l.f + 12);
     Real denom = dot(direction, normal);
@@ -1146,6 +1155,33 @@ RT_DEV Real compute_light_pdf(const DScene& sc, V3 o, V3 d) { /* :173-188 */
     Real light_select_pdf = 1.0 / sc.n_lights;
     for (int k = 0; k < sc.n_lights; ++k) total_pdf += light_pdf(sc.lights[k], o, d) * light_select_pdf;
     return total_pdf;
+}
+
+/* What a ray that leaves the scene adds to L (before the throughput-weighted sum):
+ * mis_path_integrator.h:37-67, direct_light_integrator.h:41-54; the other integrators only know
+ * the background colour.  The only infinite light flattened is the map-less EnvironmentLight,
+ * whose Le is (1,1,1) (environmental_light.h:226-229). */
+template <int INTEG>
+RT_DEV V3 miss_radiance(const DScene& sc, V3 thr, V3 ro, V3 rd, int depth, bool specular_bounce, Real prev_bsdf_pdf) {
+    if (INTEG == RTR_INTEGRATOR_MIS || INTEG == RTR_INTEGRATOR_NEE) {
+        V3 env = mk(0, 0, 0);
+        bool found = false;
+        for (int k = 0; k < sc.n_lights; ++k)
+            if (sc.lights[k].type == RTR_LIGHT_ENV_UNIFORM) {
+                if (INTEG == RTR_INTEGRATOR_NEE)
+                    env = add(env, mul(thr, mk(1, 1, 1))); /* L += throughput * Le, light by light */
+                else
+                    env = add(env, mk(1, 1, 1));
+                found = true;
+            }
+        if (found) {
+            if (INTEG == RTR_INTEGRATOR_NEE) return env;
+            if (depth == 0 || specular_bounce) return mul(thr, env);
+            const Real mis_weight = power_heuristic(prev_bsdf_pdf, compute_light_pdf(sc, ro, rd));
+            return scl(mis_weight, mul(thr, env));
+        }
+    }
+    return mul(thr, ld3(sc.background));
 }
 
 struct PathCounters {
@@ -1224,7 +1260,7 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
         const Real light_select_pdf = 1.0 / sc.n_lights;
         const Real uy = rng_next(rng); /* vec2 u(r(), r()): u.y takes the first draw (g++ order) */
         const Real ux = rng_next(rng);
-        LightSample ls = light_sample(light, rec.p, ux, uy);
+        LightSample ls = light_sample(light, rec.p, ux, uy, rng);
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
             V3 f = mat_eval<MS>(sc, rec, wo, ls.wi);
             Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));
@@ -1325,8 +1361,7 @@ __device__ __forceinline__ bool bounce(const DScene& sc, PathState& ps, uint32_t
     rec.u = 0, rec.v = 0;
     ++cnt.closest;
     if (!cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st)) {
-        /* mis_path_integrator.h:48-49 / rr_path_integrator.h:31-33; no infinite light is flattened */
-        ps.L = add(ps.L, mul(ps.thr, ld3(sc.background)));
+        ps.L = add(ps.L, miss_radiance<INTEG>(sc, ps.thr, ps.ro, ps.rd, ps.depth, ps.specular_bounce, ps.prev_bsdf_pdf));
         return false;
     }
     bool go;

@@ -25,6 +25,7 @@ struct RenderK {
     const int* tile_ids; /* owned tiles, reference dispatch numbering (renderer.h:61-62) */
     int n_tiles;
     int chunks;
+    int integrator; /* RTR_INTEGRATOR_* (the wavefront's extend stage needs it for rays that miss) */
     double* partial;             /* [n_tiles*chunks][3][RTR_BLOCK] un-normalised sums */
     unsigned long long* stats;   /* samples, closest segments, shadow segments */
     const int* cancel;           /* set by rtr_cancel() */
@@ -137,7 +138,8 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                 rec.u = 0, rec.v = 0;
                 ++cnt.closest;
                 if (!cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st)) {
-                    pk.set3(PK_L, add(pk.get3(PK_L), mul(pk.get3(PK_THR), ld3(sc.background))));
+                    pk.set3(PK_L, add(pk.get3(PK_L), miss_radiance<INTEG>(sc, pk.get3(PK_THR), ps.ro, ps.rd, ps.depth,
+                                                                          ps.specular_bounce, pk.get(PK_PDF))));
                     ended = true;
                 } else {
                     ps.thr = pk.get3(PK_THR);
@@ -288,7 +290,8 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_lights(const DScene sc, rtr_
     if (k >= n) return;
     rtr_light_record r = recs[k];
     const rtr_light& l = sc.lights[r.light];
-    LightSample s = light_sample(l, ld3(r.p), r.u[0], r.u[1]);
+    uint32_t rng = 0x2545F491u; /* the uniform environment light draws its direction itself */
+    LightSample s = light_sample(l, ld3(r.p), r.u[0], r.u[1], rng);
     r.Li[0] = s.Li.x, r.Li[1] = s.Li.y, r.Li[2] = s.Li.z;
     r.wi[0] = s.wi.x, r.wi[1] = s.wi.y, r.wi[2] = s.wi.z;
     r.pdf = s.pdf, r.dist = s.dist, r.is_delta = s.is_delta, r.pad2 = 0;

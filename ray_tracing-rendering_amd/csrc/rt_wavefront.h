@@ -217,9 +217,15 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4) wf_extend(const DScene* __restri
             rec.u = 0, rec.v = 0;
             S.n_closest[slot] += 1;
             if (!cast_closest<TRAV>(sc, ro, rd, tm, rec, rng, st)) {
-                /* mis_path_integrator.h:48-49, rr_path_integrator.h:31-33 */
-                V3 L = add(ldv(S.lx, S.ly, S.lz, slot), mul(ldv(S.tx, S.ty, S.tz, slot), ld3(sc.background)));
-                stv(S.lx, S.ly, S.lz, slot, L);
+                /* mis_path_integrator.h:37-67, rr_path_integrator.h:31-33 */
+                const V3 thr = ldv(S.tx, S.ty, S.tz, slot);
+                V3 add_l;
+                if (P.integrator == RTR_INTEGRATOR_MIS)
+                    add_l = miss_radiance<RTR_INTEGRATOR_MIS>(sc, thr, ro, rd, flags >> 8, (flags & WF_SPEC) != 0,
+                                                              S.pdf[slot]);
+                else
+                    add_l = mul(thr, ld3(sc.background));
+                stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), add_l));
                 S.flags[slot] = flags | WF_NEED_SAMPLE;
                 S.rng[slot] = rng;
                 break;

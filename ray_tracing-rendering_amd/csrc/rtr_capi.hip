@@ -577,6 +577,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     P.x0 = p->x0, P.y0 = p->y0, P.x1 = p->x1, P.y1 = p->y1;
     P.spp = p->spp, P.max_depth = p->max_depth, P.rr_start = p->rr_start_depth;
     P.seed = p->seed;
+    P.integrator = p->integrator;
     std::vector<int> tiles = owned_tiles(*p, P.tiles_x, P.tiles_y);
     P.n_tiles = (int)tiles.size();
     c->stats = rtr_render_stats{};

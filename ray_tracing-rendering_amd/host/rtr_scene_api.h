@@ -677,15 +677,19 @@ class DirectionalLight : public Light {
     vec3 direction;
     color L;
 };
-/* The HDR environment light is a scene-description placeholder for now: it
- * constructs, but flatten() refuses scenes that use it. */
+/* EnvironmentLight (lighting/environmental_light.h:120-374).  No HDR decoder ships with this layer
+ * and none of the reference's maps exist, so the map is always "missing", which is the
+ * reference's own behaviour in this checkout: a uniform white sky (:126-131,187-192,226-229,293-294). */
 class EnvironmentLight : public Light {
   public:
-    EnvironmentLight(const char* map_filename) : filename(map_filename ? map_filename : "") {}
+    EnvironmentLight(const char* map_filename) : filename(map_filename ? map_filename : "") {
+        std::cerr << "ERROR: Could not load HDR environment map: " << filename << std::endl;
+    }
     bool is_infinite() const override { return true; }
-    bool rtr_flatten(rtr_light&, std::string& why) const override {
-        why = "EnvironmentLight is not on the device yet (SURVEY 8f N2)";
-        return false;
+    bool rtr_flatten(rtr_light& out, std::string&) const override {
+        out = rtr_light{};
+        out.type = RTR_LIGHT_ENV_UNIFORM;
+        return true;
     }
     std::string filename;
 };

@@ -288,7 +288,7 @@ def test_next_integrators(ctx, sid, integ, img_name):
     assert e.value.code == A.RTR_ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("sid", [15, 17, 18])
+@pytest.mark.parametrize("sid", [15, 17, 18, 19])
 def test_delta_lights(ctx, sid):
     """PointLight (scene 15), DirectionalLight (17), SpotLight (18): light records,
     per-sample records and images vs the reference, both pipelines."""
@@ -298,7 +298,8 @@ def test_delta_lights(ctx, sid):
     for f in ("Li", "wi", "pdf", "dist", "pdf_dir"):
         assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
     assert np.array_equal(out["is_delta"], gold["is_delta"])
-    cases = [(4, "img_scene%02d_i4_64_spp16.f64" % sid)] + ([(3, "img_scene18_i3_64_spp16.f64")] if sid == 18 else [])
+    cases = [(4, "img_scene%02d_i4_64_spp16.f64" % sid)] + \
+            ([(3, "img_scene%02d_i3_64_spp16.f64" % sid)] if sid in (18, 19) else [])  # 19: uniform EnvironmentLight
     for integ, img_name in cases:
         name = "li_scene%02d_i%d.bin" % (sid, integ)
         info = G.MANIFEST["files"][name]
