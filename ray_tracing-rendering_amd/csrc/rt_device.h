@@ -1153,7 +1153,10 @@ RT_DEV Real power_heuristic(Real pdf_a, Real pdf_b) { /* :165-170 */
 RT_DEV Real compute_light_pdf(const DScene& sc, V3 o, V3 d) { /* :173-188 */
     Real total_pdf = 0.0;
     Real light_select_pdf = 1.0 / sc.n_lights;
-    for (int k = 0; k < sc.n_lights; ++k) total_pdf += light_pdf(sc.lights[k], o, d) * light_select_pdf;
+    for (int k = 0; k < sc.n_lights; ++k) {
+        const rtr_light l = ld_const(sc.lights, k); /* wave-uniform index: scalar loads */
+        total_pdf += light_pdf(l, o, d) * light_select_pdf;
+    }
     return total_pdf;
 }
 
@@ -1256,11 +1259,16 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
     /* material::is_specular() is never overridden, so NEE runs at every hit */
     if (have_lights) {
         const int light_idx = rng_int(rng, 0, sc.n_lights - 1);
-        const rtr_light& light = sc.lights[light_idx];
         const Real light_select_pdf = 1.0 / sc.n_lights;
         const Real uy = rng_next(rng); /* vec2 u(r(), r()): u.y takes the first draw (g++ order) */
         const Real ux = rng_next(rng);
-        LightSample ls = light_sample(light, rec.p, ux, uy, rng);
+        LightSample ls;
+        if (sc.n_lights == 1) { /* the usual case: the record comes in through scalar loads, not 34 VGPRs */
+            const rtr_light l0 = ld_const(sc.lights, 0);
+            ls = light_sample(l0, rec.p, ux, uy, rng);
+        } else {
+            ls = light_sample(sc.lights[light_idx], rec.p, ux, uy, rng);
+        }
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
             V3 f = mat_eval<MS>(sc, rec, wo, ls.wi);
             Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));

@@ -54,7 +54,7 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
  * ("parked"), so it does not occupy VGPRs across the traversal loops: throughput, radiance of
  * the sample, pixel sum, previous BSDF pdf and the pending light contribution.  Word k of lane l
  * is park[k * RTR_BLOCK + l] (8-byte words: conflict-free ds_read_b64 / ds_write_b64). */
-#define RT_PARK_WORDS 13
+#define RT_PARK_WORDS 19
 struct Park {
     double* base;
     RT_DEV V3 get3(int k) const { return mk(base[k * RTR_BLOCK], base[(k + 1) * RTR_BLOCK], base[(k + 2) * RTR_BLOCK]); }
@@ -64,7 +64,7 @@ struct Park {
     RT_DEV double get(int k) const { return base[k * RTR_BLOCK]; }
     RT_DEV void set(int k, double v) const { base[k * RTR_BLOCK] = v; }
 };
-enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_CONTRIB = 9, PK_PDF = 12 };
+enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_CONTRIB = 9, PK_PDF = 12, PK_SWI = 13, PK_STMAX = 16, PK_NCLOSEST = 17, PK_NSHADOW = 18 };
 
 template <int INTEG, int TRAV, int MS>
 __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES : 2)
@@ -119,31 +119,38 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
          * stays in lockstep although path lengths differ; the sums still see their terms in the
          * reference's order (emission, then the light sample of the same bounce). */
         auto begin_sample = [&]() { /* renderer.h:73-75 under the per-sample seed */
-            rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
-            const Real u = (i + rng_next(rng)) / (P.W - 1);
-            const Real v = (j + rng_next(rng)) / (P.H - 1);
+            int pi, pj;
+            bool in_region;
+            tile_pixel(P, slot, threadIdx.x, pi, pj, in_region); /* recomputed: not worth two live registers */
+            rng = rtr_sample_seed_inline(P.seed, P.W, pi, pj, s);
+            const Real u = (pi + rng_next(rng)) / (P.W - 1);
+            const Real v = (pj + rng_next(rng)) / (P.H - 1);
             camera_get_ray(sc.camera, u, v, rng, ps.ro, ps.rd, ps.tm);
             ps.depth = 0, ps.specular_bounce = false;
             pk.set3(PK_THR, mk(1.0, 1.0, 1.0));
             pk.set3(PK_L, mk(0.0, 0.0, 0.0));
             pk.set(PK_PDF, 0.0);
         };
+        /* cast counters live in LDS as well (exact in a double up to 2^53) */
+        pk.set(PK_NCLOSEST, 0.0);
+        pk.set(PK_NSHADOW, 0.0);
         if (!done) begin_sample();
         while (!done) {
             bool pending = false, ended = false;
-            V3 swi = mk(0, 0, 0);
-            Real stmax = 0;
             {
                 Hit rec;
                 rec.u = 0, rec.v = 0;
-                ++cnt.closest;
+                pk.set(PK_NCLOSEST, pk.get(PK_NCLOSEST) + 1.0);
                 if (!cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st)) {
                     pk.set3(PK_L, add(pk.get3(PK_L), miss_radiance<INTEG>(sc, pk.get3(PK_THR), ps.ro, ps.rd, ps.depth,
                                                                           ps.specular_bounce, pk.get(PK_PDF))));
                     ended = true;
                 } else {
                     ps.thr = pk.get3(PK_THR);
-                    ps.L = pk.get3(PK_L);
+                    /* shading adds at most ONE term (the emission) to L before the light sample is
+                     * resolved, so it can start from zero and be added to the parked sum afterwards:
+                     * L + e is the same rounding as the reference's L += e */
+                    ps.L = mk(0.0, 0.0, 0.0);
                     ps.prev_bsdf_pdf = pk.get(PK_PDF);
                     bool go;
                     if (INTEG == RTR_INTEGRATOR_RR) {
@@ -154,23 +161,25 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                         const V3 wo = neg(unit(ps.rd));
                         ShadowReq rq;
                         shade_a_mis<MS, INTEG>(sc, ps, rec, wo, rng, rq);
-                        if (rq.valid) {
+                        if (rq.valid) { /* parked until the shadow ray is cast */
                             pending = true;
-                            swi = rq.wi, stmax = rq.tmax;
+                            pk.set3(PK_SWI, rq.wi);
+                            pk.set(PK_STMAX, rq.tmax);
                             pk.set3(PK_CONTRIB, rq.contrib);
                         }
                         go = shade_b_mis<MS, INTEG>(sc, ps, rec, wo, rng, P.rr_start);
                     }
                     ps.ro = rec.p; /* next ray origin and shadow ray origin */
                     pk.set3(PK_THR, ps.thr);
-                    pk.set3(PK_L, ps.L);
+                    if (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0) pk.set3(PK_L, add(pk.get3(PK_L), ps.L));
                     pk.set(PK_PDF, ps.prev_bsdf_pdf);
                     ended = !go || ++ps.depth >= P.max_depth;
                 }
             }
             if (pending) { /* mis_path_integrator.h:210-213, origin = the hit point = ps.ro */
-                ++cnt.shadow;
-                if (!cast_shadow<TRAV>(sc, ps.ro, swi, stmax, rng, st)) pk.set3(PK_L, add(pk.get3(PK_L), pk.get3(PK_CONTRIB)));
+                pk.set(PK_NSHADOW, pk.get(PK_NSHADOW) + 1.0);
+                if (!cast_shadow<TRAV>(sc, ps.ro, pk.get3(PK_SWI), pk.get(PK_STMAX), rng, st))
+                    pk.set3(PK_L, add(pk.get3(PK_L), pk.get3(PK_CONTRIB)));
             }
             if (ended) {
                 pk.set3(PK_ACC, add(pk.get3(PK_ACC), pk.get3(PK_L))); /* renderer.h:77-78 */
@@ -180,6 +189,8 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                 if (!done) begin_sample();
             }
         }
+        cnt.closest = (uint32_t)pk.get(PK_NCLOSEST);
+        cnt.shadow = (uint32_t)pk.get(PK_NSHADOW);
     }
     const V3 acc = pk.get3(PK_ACC);
     double* out = P.partial + (size_t)blockIdx.x * 3 * RTR_BLOCK + threadIdx.x;
