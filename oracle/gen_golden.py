@@ -50,12 +50,12 @@ def main():
     note("rng.bin", cmd, info)
 
     # flattened scenes (walked from the reference's own object graph)
-    for sid in (7, 21, 23, 9, 22, 15, 17, 18, 19):
+    for sid in (7, 21, 23, 9, 22, 15, 17, 18, 19, 1, 8):
         name = "scene%02d.rtrs" % sid
         path = os.path.join(GOLD, name)
         cmd, info = run("dump-scene", sid, SCENE_SEED, path)
         raw_sha = sha(path)
-        if os.path.getsize(path) > 100_000:  # scene 9 / 22: keep the repo small
+        if os.path.getsize(path) > 60_000:  # scene 9 / 22 / 1: keep the repo small
             with open(path, "rb") as f:
                 data = f.read()
             with open(path + ".gz", "wb") as f:
@@ -66,7 +66,7 @@ def main():
             note(name, cmd, info, raw_sha256=raw_sha)
 
     # closest-hit vectors on whole scenes
-    for sid, n in ((21, 1024), (23, 1024), (9, 1536)):
+    for sid, n in ((21, 1024), (23, 1024), (9, 1536), (1, 768), (8, 768)):
         name = "hits_scene%02d.bin" % sid
         cmd, info = run("hits", sid, SCENE_SEED, n, 777 + sid, os.path.join(GOLD, name))
         note(name, cmd, info, scene=sid)
@@ -89,7 +89,10 @@ def main():
              # delta lights (point 15, directional 17, spot 18)
              (15, 4, 64, 16, 1), (17, 4, 64, 16, 1), (18, 4, 64, 16, 1), (18, 3, 64, 16, 1),
              # the map-less EnvironmentLight (uniform white sky): scene 19
-             (19, 4, 64, 16, 1), (19, 3, 64, 16, 1)]
+             (19, 4, 64, 16, 1), (19, 3, 64, 16, 1),
+             # scene 1 = RTIOW random spheres (checker, metal, glass, moving spheres, thin lens; 485-leaf BVH)
+             # scene 8 = Cornell smoke (media whose boundaries sit under translate/rotate_y)
+             (1, 1, 64, 16, 1), (8, 1, 64, 16, 1)]
     for sid, integ, W, spp, seed in cases:
         name = "li_scene%02d_i%d.bin" % (sid, integ)
         n_li = 2048 if (sid, integ) in ((7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4)) else 768

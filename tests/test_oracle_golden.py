@@ -40,7 +40,7 @@ def test_sample_seed_never_zero():
     assert len(seen) > 250  # distinct streams
 
 
-@pytest.mark.parametrize("sid", [21, 23, 9, 4])
+@pytest.mark.parametrize("sid", [21, 23, 9, 4, 1, 8])
 def test_closest_hit_vectors(sid):
     """hittable::hit on whole scenes: BVH order, wrappers, primitives, media RNG (SURVEY 3.4)."""
     sc = G.scene(sid)
@@ -60,7 +60,7 @@ def test_closest_hit_vectors(sid):
     for f in ("u", "v"):
         assert np.array_equal(_bits(out[f][uv]), _bits(gold[f][uv])), f
         assert np.all(np.isnan(out[f][h & ~uv]))
-    if sid == 9:  # media consumed RNG inside traversal
+    if sid in (9, 8):  # media consumed RNG inside traversal
         assert np.any(gold["rng_in"] != gold["rng_out"])
 
 
@@ -102,7 +102,7 @@ def test_light_vectors(sid):
 
 
 LI_CASES = [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4), (7, 0), (23, 2), (21, 3), (23, 3),
-            (15, 4), (17, 4), (18, 4), (18, 3), (4, 1), (19, 4), (19, 3)]
+            (15, 4), (17, 4), (18, 4), (18, 3), (4, 1), (19, 4), (19, 3), (1, 1), (8, 1)]
 
 
 @pytest.mark.parametrize("sid,integ", LI_CASES)
@@ -132,7 +132,8 @@ IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_
              "img_scene21_i4_128_spp32.f64", "img_scene07_i0_48_spp8.f64", "img_scene23_i2_64_spp16.f64",
              "img_scene21_i3_64_spp16.f64", "img_scene23_i3_64_spp16.f64", "img_scene15_i4_64_spp16.f64",
              "img_scene17_i4_64_spp16.f64", "img_scene18_i4_64_spp16.f64", "img_scene18_i3_64_spp16.f64",
-             "img_scene04_i1_64_spp16.f64", "img_scene19_i4_64_spp16.f64", "img_scene19_i3_64_spp16.f64"]
+             "img_scene04_i1_64_spp16.f64", "img_scene19_i4_64_spp16.f64", "img_scene19_i3_64_spp16.f64", "img_scene01_i1_64_spp16.f64",
+             "img_scene08_i1_64_spp16.f64"]
 
 
 @pytest.mark.parametrize("name", IMG_CASES)
