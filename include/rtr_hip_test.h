@@ -23,7 +23,8 @@ typedef struct rtr_scene_info {
     int32_t fast_ok;     /* a compiled scene exists (no media): the order-free traversal is the default */
     int32_t fast_instances, fast_refs, fast_stack_words;
     int32_t compiled_subtrees; /* media scenes: media-free subtrees compiled inside the reference-order walk */
-    int32_t reserved[3];
+    int32_t program_steps;     /* media scenes: steps of the ray-cast program (0: media not directly under the root list) */
+    int32_t reserved[2];
 } rtr_scene_info;
 
 /* Host-only: the checks rtr_upload_scene() runs before touching the GPU.  Returns RTR_OK,

@@ -23,6 +23,8 @@ struct CompiledScene {
     std::vector<FRef> ref;
     std::vector<int32_t> exits;
     std::vector<FBvh> bvh;
+    std::vector<FStep> steps; /* ray-cast program of a scene with media (empty: none could be built) */
+    int step_tail = 0;
     int stack_words = 1;
     bool ok = false;
 };
@@ -32,6 +34,7 @@ namespace rtc {
 constexpr int kLinearMax = 12; /* instances with more references get a box tree */
 constexpr int kLeafMax = 4;
 constexpr int kMaxInstances = 64;
+constexpr int kMaxTreeDepth = 56; /* bounds the per-lane LDS stack of the box-tree traversal */
 
 struct Box {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -202,48 +205,101 @@ struct Builder {
         }
     }
 
-    int build_tree(std::vector<PendingRef>& refs, int lo, int hi, int depth, int& max_depth) {
+    static double half_area(const Box& b) {
+        const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+        return x * y + y * z + z * x;
+    }
+
+    /* Box tree over refs[lo, hi) (indices local to the instance; `ref_base` makes them global):
+     * binned surface-area heuristic, median split of the widest centroid axis when the bins do not
+     * separate anything.  Returns the link of the subtree (see FBvh) and its box. */
+    int build_tree(std::vector<PendingRef>& refs, int lo, int hi, int ref_base, int depth, int& max_depth, Box& box) {
+        box = Box();
+        for (int k = lo; k < hi; ++k) box.grow(refs[k].local);
+        const int n = hi - lo;
+        if (n <= kLeafMax) return -1 - (((ref_base + lo) << 3) | (n - 1));
         max_depth = std::max(max_depth, depth);
-        Box b;
-        for (int k = lo; k < hi; ++k) b.grow(refs[k].local);
-        const int me = (int)out.bvh.size();
-        out.bvh.push_back(FBvh{});
-        FBvh node{};
-        for (int c = 0; c < 3; ++c) node.bmin[c] = b.lo[c], node.bmax[c] = b.hi[c];
-        if (hi - lo <= kLeafMax) {
-            node.left = lo; /* patched to the global reference index by the caller */
-            node.right = -(hi - lo);
+        auto centre = [&](int k, int c) { return 0.5 * (refs[k].local.lo[c] + refs[k].local.hi[c]); };
+        Box cb;
+        for (int k = lo; k < hi; ++k) {
+            const double ctr[3] = {centre(k, 0), centre(k, 1), centre(k, 2)};
+            cb.grow(ctr);
+        }
+        constexpr int kBins = 16;
+        int best_axis = -1, best_bin = -1;
+        double best_cost = INFINITY;
+        if (depth < kMaxTreeDepth - 8) { /* deep, badly separable sets fall back to balanced median splits */
+            for (int axis = 0; axis < 3; ++axis) {
+                const double c0 = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+                if (!(ext > 0)) continue;
+                Box bb[kBins];
+                int cnt[kBins] = {0};
+                for (int k = lo; k < hi; ++k) {
+                    const int b = std::min(kBins - 1, (int)(kBins * ((centre(k, axis) - c0) / ext)));
+                    bb[b].grow(refs[k].local);
+                    ++cnt[b];
+                }
+                Box right_box[kBins];
+                int right_cnt[kBins];
+                Box acc;
+                int c = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    if (cnt[b]) acc.grow(bb[b]);
+                    c += cnt[b];
+                    right_box[b] = acc, right_cnt[b] = c;
+                }
+                acc = Box(), c = 0;
+                for (int b = 0; b + 1 < kBins; ++b) { /* split between bin b and b + 1 */
+                    if (cnt[b]) acc.grow(bb[b]);
+                    c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    const double cost = half_area(acc) * c + half_area(right_box[b + 1]) * right_cnt[b + 1];
+                    if (cost < best_cost) best_cost = cost, best_axis = axis, best_bin = b;
+                }
+            }
+        }
+        int mid;
+        if (best_axis >= 0) {
+            const double c0 = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
+            auto it = std::partition(refs.begin() + lo, refs.begin() + hi, [&](const PendingRef& r) {
+                const double ctr = 0.5 * (r.local.lo[best_axis] + r.local.hi[best_axis]);
+                return std::min(kBins - 1, (int)(kBins * ((ctr - c0) / ext))) <= best_bin;
+            });
+            mid = (int)(it - refs.begin());
         } else {
             int axis = 0;
-            double ext = -1;
-            Box cb;
-            for (int k = lo; k < hi; ++k) {
-                double ctr[3];
-                for (int c = 0; c < 3; ++c) ctr[c] = 0.5 * (refs[k].local.lo[c] + refs[k].local.hi[c]);
-                cb.grow(ctr);
-            }
-            for (int c = 0; c < 3; ++c)
-                if (cb.hi[c] - cb.lo[c] > ext) ext = cb.hi[c] - cb.lo[c], axis = c;
-            const int mid = (lo + hi) / 2;
+            for (int c = 1; c < 3; ++c)
+                if (cb.hi[c] - cb.lo[c] > cb.hi[axis] - cb.lo[axis]) axis = c;
+            mid = (lo + hi) / 2;
             std::nth_element(refs.begin() + lo, refs.begin() + mid, refs.begin() + hi,
                              [axis](const PendingRef& x, const PendingRef& y) {
                                  return x.local.lo[axis] + x.local.hi[axis] < y.local.lo[axis] + y.local.hi[axis];
                              });
-            node.left = build_tree(refs, lo, mid, depth + 1, max_depth);
-            node.right = build_tree(refs, mid, hi, depth + 1, max_depth);
         }
+        const int me = (int)out.bvh.size();
+        out.bvh.push_back(FBvh{});
+        Box bl, br;
+        const int l = build_tree(refs, lo, mid, ref_base, depth + 1, max_depth, bl);
+        const int r = build_tree(refs, mid, hi, ref_base, depth + 1, max_depth, br);
+        FBvh node{};
+        for (int c = 0; c < 3; ++c) {
+            node.lmin[c] = bl.lo[c], node.lmax[c] = bl.hi[c];
+            node.rmin[c] = br.lo[c], node.rmax[c] = br.hi[c];
+        }
+        node.left = l, node.right = r;
         out.bvh[me] = node;
         return me;
     }
 
-    /* compile the subtree under `root`; returns the sub-scene index or -1 (media / too fragmented) */
-    int run(int root) {
+    int run(int root) { return run(std::vector<int>{root}); }
+    /* compile the subtrees under `roots` into one sub-scene; returns its index or -1 (media / too fragmented) */
+    int run(const std::vector<int>& roots) {
         /* camera rays carry a time in [time0, time1], shadow rays time 0 (mis_path_integrator.h:210) */
         t_lo = std::min(0.0, std::min(s->camera.time0, s->camera.time1));
         t_hi = std::max(0.0, std::max(s->camera.time0, s->camera.time1));
         const size_t mark[6] = {out.inst.size(), out.xf.size(), out.ref.size(), out.exits.size(), out.bvh.size(), 0};
         inst_base = (int)out.inst.size();
-        walk(root);
+        for (int root : roots) walk(root);
         if (too_complex || (int)out.inst.size() == inst_base) { /* undo */
             out.inst.resize(mark[0]), out.xf.resize(mark[1]), out.ref.resize(mark[2]), out.exits.resize(mark[3]);
             out.bvh.resize(mark[4]);
@@ -255,12 +311,10 @@ struct Builder {
             std::vector<PendingRef>& refs = pending[ii - inst_base];
             I.ref_first = (int)out.ref.size();
             I.n_ref = (int)refs.size();
-            const int first_bvh = (int)out.bvh.size();
             if ((int)refs.size() > kLinearMax) {
                 int depth = 0;
-                I.bvh_root = build_tree(refs, 0, (int)refs.size(), 1, depth);
-                for (size_t b = first_bvh; b < out.bvh.size(); ++b)
-                    if (out.bvh[b].right < 0) out.bvh[b].left += I.ref_first;
+                Box all;
+                I.bvh_root = build_tree(refs, 0, (int)refs.size(), I.ref_first, 1, depth, all);
                 stack = std::max(stack, depth + 2);
             }
             Box local;
@@ -393,5 +447,72 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
         }
     }
     cs.ok = false;
+    /* the step program (struct FStep): the reference's visiting order (bvh_node: left then right,
+     * also when both are the same object, bvh.h:56-58; hittable_list: in order) over the part of
+     * the graph that holds media; media-free subtrees met on the way are the geometry items */
+    {
+        std::vector<int> items;
+        bool possible = true;
+        std::vector<int> walk_stack{scene->root};
+        while (!walk_stack.empty() && possible) {
+            const int ix = walk_stack.back();
+            walk_stack.pop_back();
+            const rtr_node& n = scene->nodes[ix];
+            if (!facts.media[ix] || n.type == RTR_NODE_MEDIUM) {
+                items.push_back(ix);
+            } else if (n.type == RTR_NODE_LIST) {
+                for (int k = n.b - 1; k >= 0; --k) walk_stack.push_back(scene->list_children[n.a + k]);
+            } else if (n.type == RTR_NODE_BVH) {
+                walk_stack.push_back(n.b), walk_stack.push_back(n.a);
+            } else {
+                possible = false; /* a medium under a transform: the reference-order walk handles it */
+            }
+        }
+        const size_t mark[7] = {cs.inst.size(), cs.xf.size(), cs.ref.size(), cs.exits.size(), cs.bvh.size(), cs.subs.size(),
+                                (size_t)cs.stack_words};
+        std::vector<int> group;
+        auto flush = [&]() {
+            if (group.empty() || !possible) return;
+            rtc::Builder b(cs);
+            b.s = scene;
+            const int sub = b.run(group);
+            group.clear();
+            if (sub < 0) {
+                possible = false;
+                return;
+            }
+            FStep st{};
+            st.kind = 0, st.sub = sub;
+            cs.steps.push_back(st);
+        };
+        for (size_t k = 0; k < items.size() && possible; ++k) {
+            const rtr_node& n = scene->nodes[items[k]];
+            if (n.type != RTR_NODE_MEDIUM) {
+                group.push_back(items[k]);
+                continue;
+            }
+            flush();
+            if (!possible) break;
+            rtc::Builder b(cs);
+            b.s = scene;
+            const int sub = b.run(n.a);
+            if (sub < 0) {
+                possible = false;
+                break;
+            }
+            FStep st{};
+            st.kind = 1, st.sub = sub, st.mat = n.b, st.neg_inv_density = n.f[0];
+            cs.steps.push_back(st);
+            cs.step_tail = (int)cs.steps.size();
+        }
+        flush();
+        if (!possible) { /* undo */
+            cs.inst.resize(mark[0]), cs.xf.resize(mark[1]), cs.ref.resize(mark[2]), cs.exits.resize(mark[3]);
+            cs.bvh.resize(mark[4]), cs.subs.resize(mark[5]);
+            cs.stack_words = (int)mark[6];
+            cs.steps.clear();
+            cs.step_tail = 0;
+        }
+    }
     return cs;
 }

@@ -173,7 +173,10 @@ struct DScene {
     const struct FBvh* fbvh;
     const struct FSub* fsub; /* compiled sub-scenes: [0] = whole scene when it has no media */
     int32_t n_finst;         /* instances of sub-scene 0 (0 = none) */
-    int32_t fast_pad;
+    int32_t n_fstep;         /* steps of the ray-cast program of a scene with media (0 = none) */
+    const struct FStep* fstep;
+    int32_t fstep_tail;      /* first step after the last medium */
+    int32_t fstep_pad;
 };
 
 /*
@@ -206,10 +209,16 @@ struct FRef {
     int32_t n_exit;
     int32_t pad;        /* host side: visiting order (copied into fprim[].reserved) */
 };
+/* One INNER node of an instance's box tree: the boxes of both children next to their links, so a
+ * traversal step costs one record fetch.  A link >= 0 is another inner node; a negative link is a
+ * leaf, -1 - ((first_reference << 3) | (count - 1)), count <= 8.  The tree is built with a binned
+ * surface-area heuristic (rt_compile.h); any tree is valid, the boxes only prune. */
 struct FBvh {
-    double bmin[3], bmax[3];
-    int32_t left, right; /* right < 0: leaf holding references [left, left - right) */
+    double lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
 };
+#define RT_BVH_DONE (-2147483647 - 1) /* traversal sentinel: nothing left on the stack */
 /* A compiled sub-scene = a range of instances.  Scenes WITH media keep the reference-order walk
  * for the (small) part of the graph the media live in, and every large media-free subtree under
  * it is compiled on its own: the walk meets it as one node of type RT_NODE_COMPILED at the place
@@ -219,6 +228,24 @@ struct FSub {
     int32_t inst_first, n_inst;
 };
 #define RT_NODE_COMPILED 11 /* device-only node type: a = sub-scene index */
+/* Ray-cast program of a scene whose constant_media sit under bvh_nodes / hittable_lists only: the
+ * reference's visiting order cut into steps -- a medium is a step of its own, every run of
+ * media-free objects between two media is merged into ONE compiled sub-scene.  Both containers hand
+ * each member the closest t so far and keep the closest record (hittable_list.h:33-47,
+ * bvh.h:40-50), so merging neighbours changes nothing, and a medium sees the t_max the reference
+ * passes to it: its random draw (constant_medium.h:88) happens under the same condition, in the
+ * same sequence.  What the program drops are the box tests of the bvh_nodes above a medium; a box
+ * the ray misses within [t_min, t_max] contains no boundary segment there either, so the medium
+ * returns before drawing -- the two can differ only when a boundary hit and a box face coincide to
+ * the last bit (tests/: program == reference-order walk on every golden scene).  All lanes of a
+ * wave run the same steps; there is no per-node interpretation left on this path. */
+struct FStep {
+    int32_t kind; /* 0: geometry sub-scene `sub`; 1: constant_medium with boundary sub-scene `sub` */
+    int32_t sub;
+    int32_t mat;  /* medium: phase function material */
+    int32_t pad;
+    double neg_inv_density;
+};
 
 struct Hit { /* geometry/hittable.h:10-23 */
     V3 p, n;
@@ -594,36 +621,42 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                 }
             }
         } else {
+            /* while-while traversal: every lane first walks down to its next leaf, then the wave
+             * tests leaf primitives together (the expensive, exact part) */
             int sp = sp0;
-            st.put(sp++, I.bvh_root);
-            while (sp > sp0) {
-                const FBvh& b = sc.fbvh[st.get(--sp)];
-                if (b.right < 0) {
-                    for (int r = b.left; r < b.left - b.right; ++r) {
-                        Real t;
-                        if (fast_ref_hit(sc, r, lo, ld, time, tmin, tmax, t)) {
-                            tmax = t;
-                            hit_ref = r;
-                            hit_inst = ii;
-                            if (ANY) return true;
-                        }
+            int node = I.bvh_root;
+            while (true) {
+                while (node >= 0) {
+                    const FBvh& b = sc.fbvh[node];
+                    Real tl, tr;
+                    const bool hl = box_enter(b.lmin, b.lmax, lo, linv, tmin, tmax, tl);
+                    const bool hr = box_enter(b.rmin, b.rmax, lo, linv, tmin, tmax, tr);
+                    const int cl = b.left, cr = b.right;
+                    if (hl && hr) { /* nearer child first */
+                        const bool left_first = tl <= tr;
+                        st.put(sp++, left_first ? cr : cl);
+                        node = left_first ? cl : cr;
+                    } else if (hl) {
+                        node = cl;
+                    } else if (hr) {
+                        node = cr;
+                    } else {
+                        node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
                     }
-                    continue;
                 }
-                const FBvh& L = sc.fbvh[b.left];
-                const FBvh& R = sc.fbvh[b.right];
-                Real tl, tr;
-                const bool hl = box_enter(L.bmin, L.bmax, lo, linv, tmin, tmax, tl);
-                const bool hr = box_enter(R.bmin, R.bmax, lo, linv, tmin, tmax, tr);
-                if (hl && hr) { /* nearer child first */
-                    const bool left_first = tl <= tr;
-                    st.put(sp++, left_first ? b.right : b.left);
-                    st.put(sp++, left_first ? b.left : b.right);
-                } else if (hl) {
-                    st.put(sp++, b.left);
-                } else if (hr) {
-                    st.put(sp++, b.right);
+                if (node == RT_BVH_DONE) break;
+                const int code = -1 - node;
+                const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
+                for (int r = r0; r < r1; ++r) {
+                    Real t;
+                    if (fast_ref_hit(sc, r, lo, ld, time, tmin, tmax, t)) {
+                        tmax = t;
+                        hit_ref = r;
+                        hit_inst = ii;
+                        if (ANY) return true;
+                    }
                 }
+                node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
             }
         }
     }
@@ -682,18 +715,85 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
 #define RT_TRAV_EXACT 0
 #define RT_TRAV_MEDIA 1
 #define RT_TRAV_FAST 2
+#define RT_TRAV_PROGRAM 3 /* scenes with media: the step program (struct FStep) */
+
+/* Run the ray-cast program over [tmin, tmax].  Returns whether anything was hit; then `tmax` is
+ * the hit's t and either `med` >= 0 (the step of the medium that scattered the ray) or
+ * (`ref`, `inst`) name the surface.  One trace_fast call site serves the geometry steps and both
+ * boundary casts of a medium (constant_medium.h:62-66). */
+template <bool ANY>
+__device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real time, Real tmin, Real& tmax, int& ref,
+                                            int& inst, int& med, uint32_t& rng, const Stack st) {
+    ref = -1, inst = -1, med = -1;
+    bool any = false;
+    const int n_steps = sc.n_fstep;
+    for (int k = 0; k < n_steps; ++k) {
+        /* a shadow ray that is blocked may stop once no medium is left to draw */
+        if (ANY && any && k >= sc.fstep_tail) break;
+        const FStep step = ld_const(sc.fstep, k);
+        const FSub sub = ld_const(sc.fsub, step.sub);
+        const bool medium = step.kind != 0;
+        Real lo = medium ? -RT_INF : tmin;
+        Real t1 = 0;
+        const int passes = medium ? 2 : 1;
+#pragma nounroll
+        for (int pass = 0; pass < passes; ++pass) {
+            Real t = medium ? RT_INF : tmax;
+            int r, i;
+            const bool h = trace_fast<false>(sc, sub.inst_first, sub.n_inst, o, d, time, lo, t, r, i, st, 0);
+            if (!medium) {
+                if (h) tmax = t, ref = r, inst = i, med = -1, any = true;
+            } else if (!h) {
+                break;
+            } else if (pass == 0) {
+                t1 = t;
+                lo = t + 0.0001;
+            } else { /* constant_medium.h:68-103 */
+                Real t2 = t;
+                if (t1 < tmin) t1 = tmin;
+                if (t2 > tmax) t2 = tmax;
+                if (!(t1 >= t2)) {
+                    if (t1 < 0) t1 = 0;
+                    const Real ray_length = len(d);
+                    const Real distance_inside_boundary = (t2 - t1) * ray_length;
+                    const Real hit_distance = step.neg_inv_density * log(rng_next(rng));
+                    if (!(hit_distance > distance_inside_boundary)) {
+                        tmax = t1 + hit_distance / ray_length;
+                        med = k, any = true;
+                    }
+                }
+            }
+        }
+    }
+    return any;
+}
 
 template <int TRAV>
 __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real time, Hit& rec, uint32_t& rng,
-                                             const Stack st) {
-    Real tmax = RT_INF;
+                                             const Stack st, Real tmin = 0.001, Real tmax = RT_INF) {
     if (TRAV == RT_TRAV_FAST) {
         int ref, inst;
-        if (!trace_fast<false>(sc, 0, sc.n_finst, o, d, time, 0.001, tmax, ref, inst, st, 0)) return false;
+        if (!trace_fast<false>(sc, 0, sc.n_finst, o, d, time, tmin, tmax, ref, inst, st, 0)) return false;
         fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec); /* scenes whose textures read (u,v) use the reference-order traversal */
         return true;
     }
-    return traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, time, 0.001, tmax, rec, rng, st, 0);
+    if (TRAV == RT_TRAV_PROGRAM) {
+        int ref, inst, med;
+        if (!run_program<false>(sc, o, d, time, tmin, tmax, ref, inst, med, rng, st)) return false;
+        if (med >= 0) { /* constant_medium.h:95-101 */
+            rec.t = tmax;
+            rec.p = add(o, scl(tmax, d));
+            rec.n = mk(1, 0, 0);
+            rec.front = true;
+            rec.mat = as_const(sc.fstep)[med].mat;
+        } else if (sc.needs_uv) {
+            fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
+        } else {
+            fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec);
+        }
+        return true;
+    }
+    return traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, time, tmin, tmax, rec, rng, st, 0);
 }
 template <int TRAV>
 __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real tmax, uint32_t& rng, const Stack st) {
@@ -701,10 +801,13 @@ __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real t
         int ref, inst;
         return trace_fast<true>(sc, 0, sc.n_finst, o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
     }
+    if (TRAV == RT_TRAV_PROGRAM) { /* the media behind a blocker still draw */
+        int ref, inst, med;
+        return run_program<true>(sc, o, d, 0.0, 0.001, tmax, ref, inst, med, rng, st);
+    }
     Hit dummy;
     return traverse<false, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, 0.0, 0.001, tmax, dummy, rng, st, 0);
 }
-
 /* ---- materials/perlin.h:21-111 -------------------------------------------------------------- */
 RT_DEV Real perlin_noise(const rtr_perlin& pn, V3 p) {
     const Real fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);

@@ -161,7 +161,19 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                         const V3 wo = neg(unit(ps.rd));
                         ShadowReq rq;
                         shade_a_mis<MS, INTEG>(sc, ps, rec, wo, rng, rq);
-                        if (rq.valid) { /* parked until the shadow ray is cast */
+                        if (TRAV == RT_TRAV_PROGRAM) {
+                            /* media draw inside the shadow cast: it keeps its place between the light
+                             * sample and the BSDF sample (mis_path_integrator.h:96-106) */
+                            if (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0) {
+                                pk.set3(PK_L, add(pk.get3(PK_L), ps.L));
+                                ps.L = mk(0.0, 0.0, 0.0);
+                            }
+                            if (rq.valid) {
+                                pk.set(PK_NSHADOW, pk.get(PK_NSHADOW) + 1.0);
+                                if (!cast_shadow<TRAV>(sc, rec.p, rq.wi, rq.tmax, rng, st))
+                                    pk.set3(PK_L, add(pk.get3(PK_L), rq.contrib));
+                            }
+                        } else if (rq.valid) { /* parked until the shadow ray is cast */
                             pending = true;
                             pk.set3(PK_SWI, rq.wi);
                             pk.set(PK_STMAX, rq.tmax);
@@ -253,6 +265,8 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hi
         int ref, inst;
         h = trace_fast<false>(sc, 0, sc.n_finst, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st, 0);
         if (h) fast_finish<true>(sc, ld3(r.o), ld3(r.d), r.time, tmax, ref, inst, rec);
+    } else if (TRAV == RT_TRAV_PROGRAM) {
+        h = cast_closest<TRAV>(sc, ld3(r.o), ld3(r.d), r.time, rec, rng, st, r.t_min, tmax);
     } else {
         h = traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, rec, rng, st, 0);
     }

@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4) wf_connect(const DScene* __restr
         /* shadow_ray origin = rec.p (:210); the hit record outlives the shade stage */
         const V3 o = ldv(S.hpx, S.hpy, S.hpz, slot);
         const V3 wi = ldv(S.swx, S.swy, S.swz, slot);
-        const bool MEDIA = TRAV == RT_TRAV_MEDIA;
+        const bool MEDIA = TRAV == RT_TRAV_MEDIA || TRAV == RT_TRAV_PROGRAM;
         uint32_t rng = MEDIA ? S.rng[slot] : 1u;
         S.n_shadow[slot] += 1;
         const bool hit = cast_shadow<TRAV>(sc, o, wi, S.stmax[slot], rng, st);
@@ -450,7 +450,7 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
     WfState S{};
     int rc = wf_alloc(pool, S, (int)n_slots_ll, sort, err);
     if (rc) return rc;
-    const bool media = trav == RT_TRAV_MEDIA;
+    const bool media = trav == RT_TRAV_MEDIA || trav == RT_TRAV_PROGRAM;
     const bool mis = integrator == RTR_INTEGRATOR_MIS;
     const dim3 block(RTR_BLOCK);
     const int n_blocks = (S.n_slots + RTR_BLOCK - 1) / RTR_BLOCK;
@@ -493,6 +493,8 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
             const int par = iter & 1;
             if (trav == RT_TRAV_FAST)
                 WF_EXTEND(RT_TRAV_FAST);
+            else if (trav == RT_TRAV_PROGRAM)
+                WF_EXTEND(RT_TRAV_PROGRAM);
             else if (media)
                 WF_EXTEND(RT_TRAV_MEDIA);
             else
@@ -515,7 +517,12 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
                 }
             } else {
                 WF_SHADE(RTR_INTEGRATOR_MIS, 1, RT_MS_FULL);
-                if (has_lights) WF_CONNECT(RT_TRAV_MEDIA);
+                if (has_lights) {
+                    if (trav == RT_TRAV_PROGRAM)
+                        WF_CONNECT(RT_TRAV_PROGRAM);
+                    else
+                        WF_CONNECT(RT_TRAV_MEDIA);
+                }
                 WF_SHADE(RTR_INTEGRATOR_MIS, 2, RT_MS_FULL);
             }
         }

@@ -37,7 +37,7 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep;
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool force_exact = false;
@@ -299,13 +299,16 @@ std::vector<int> owned_tiles(const rtr_render_params& p, int& tiles_x, int& tile
 /* which traversal a call uses: the compiled scene unless it does not exist or the caller asks
  * for the reference's visiting order */
 int pick_trav(const rtr_context* c, int flags) {
-    if (c->info.has_media) return RT_TRAV_MEDIA;
+    if (c->info.has_media)
+        return c->info.program_steps > 0 && !c->force_exact && !(flags & RTR_FLAG_REFERENCE_ORDER) ? RT_TRAV_PROGRAM
+                                                                                                     : RT_TRAV_MEDIA;
     if (!c->info.fast_ok || c->info.needs_uv || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER))
         return RT_TRAV_EXACT; /* the compiled path carries no (u,v) */
     return RT_TRAV_FAST;
 }
 size_t stack_bytes(const rtr_context* c, int trav) {
-    const int words = trav == RT_TRAV_FAST ? c->fast_stack_words : c->info.stack_words + c->walk_extra_words;
+    const int words = trav == RT_TRAV_FAST || trav == RT_TRAV_PROGRAM ? c->fast_stack_words
+                                                                      : c->info.stack_words + c->walk_extra_words;
     return (size_t)words * RTR_BLOCK * sizeof(int);
 }
 
@@ -322,7 +325,7 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
     const size_t lds = stack_bytes(c, trav) + (size_t)RT_PARK_WORDS * RTR_BLOCK * sizeof(double);
     const DScene* dsc = static_cast<const DScene*>(c->b_dscene.p);
     const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
-    const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA;
+    const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
 #define RTR_LAUNCH(I, T, M)                                                                        \
     do {                                                                                           \
         int rc_ = set_lds(c, k_mega<I, T, M>, lds);                                                \
@@ -336,6 +339,8 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
                 RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_LEAN);                    \
             else                                                            \
                 RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);                    \
+        } else if (trav == RT_TRAV_PROGRAM) {                               \
+            RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);                     \
         } else if (trav == RT_TRAV_MEDIA) {                                 \
             RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);                       \
         } else {                                                            \
@@ -351,6 +356,8 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
     do {                                                   \
         if (trav == RT_TRAV_FAST)                          \
             RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);       \
+        else if (trav == RT_TRAV_PROGRAM)                  \
+            RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);    \
         else                                               \
             RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);      \
     } while (0)
@@ -414,6 +421,7 @@ int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* 
         info->fast_refs = (int32_t)cs.ref.size();
         info->fast_stack_words = cs.stack_words;
         info->compiled_subtrees = cs.n_compiled_subtrees;
+        info->program_steps = (int32_t)cs.steps.size();
     }
     return rc;
 }
@@ -463,7 +471,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -514,6 +522,8 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     if ((rc = upload(c, c->b_fexit, cs.exits.data(), sizeof(int32_t) * cs.exits.size()))) return rc;
     if ((rc = upload(c, c->b_fbvh, cs.bvh.data(), sizeof(FBvh) * cs.bvh.size()))) return rc;
     if ((rc = upload(c, c->b_fsub, cs.subs.data(), sizeof(FSub) * cs.subs.size()))) return rc;
+    if ((rc = upload(c, c->b_fstep, cs.steps.data(), sizeof(FStep) * cs.steps.size()))) return rc;
+    info.program_steps = (int32_t)cs.steps.size();
     {
         std::vector<rtr_node> prims(cs.ref.size());
         for (size_t k = 0; k < cs.ref.size(); ++k) {
@@ -533,7 +543,10 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fbvh = static_cast<const FBvh*>(c->b_fbvh.p);
     d.fsub = static_cast<const FSub*>(c->b_fsub.p);
     d.n_finst = cs.ok ? cs.subs[0].n_inst : 0;
-    d.fast_pad = 0;
+    d.fstep = static_cast<const FStep*>(c->b_fstep.p);
+    d.n_fstep = (int32_t)cs.steps.size();
+    d.fstep_tail = cs.step_tail;
+    d.fstep_pad = 0;
     d.nodes = static_cast<const rtr_node*>(c->b_nodes.p);
     d.list_children = static_cast<const int32_t*>(c->b_kids.p);
     d.materials = static_cast<const rtr_material*>(c->b_mats.p);
@@ -613,7 +626,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
-        const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA;
+        const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
         rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean,
                               !lean && c->n_material_types > 1, trav, stack_bytes(c, trav), P, p->integrator, d_rgb,
                               row_stride, c->stream, &c->cancel_requested, &launches, c->err);
@@ -721,6 +734,9 @@ int rtr_test_hits(rtr_context* c, rtr_hit_record* recs, int64_t n) {
     if (trav == RT_TRAV_FAST) {
         if ((rc = set_lds(c, k_test_hits<RT_TRAV_FAST>, lds))) return rc;
         hipLaunchKernelGGL(k_test_hits<RT_TRAV_FAST>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
+    } else if (trav == RT_TRAV_PROGRAM) {
+        if ((rc = set_lds(c, k_test_hits<RT_TRAV_PROGRAM>, lds))) return rc;
+        hipLaunchKernelGGL(k_test_hits<RT_TRAV_PROGRAM>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
     } else if (trav == RT_TRAV_MEDIA) {
         if ((rc = set_lds(c, k_test_hits<RT_TRAV_MEDIA>, lds))) return rc;
         hipLaunchKernelGGL(k_test_hits<RT_TRAV_MEDIA>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
@@ -773,6 +789,8 @@ int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs,
     do {                                                       \
         if (trav == RT_TRAV_FAST)                              \
             RTR_LAUNCH(I, RT_TRAV_FAST);                       \
+        else if (trav == RT_TRAV_PROGRAM)                      \
+            RTR_LAUNCH(I, RT_TRAV_PROGRAM);                    \
         else if (trav == RT_TRAV_MEDIA)                        \
             RTR_LAUNCH(I, RT_TRAV_MEDIA);                      \
         else                                                   \
@@ -782,6 +800,8 @@ int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs,
     do {                                                   \
         if (trav == RT_TRAV_FAST)                          \
             RTR_LAUNCH(I, RT_TRAV_FAST);                   \
+        else if (trav == RT_TRAV_PROGRAM)                  \
+            RTR_LAUNCH(I, RT_TRAV_PROGRAM);                \
         else                                               \
             RTR_LAUNCH(I, RT_TRAV_MEDIA);                  \
     } while (0)
