@@ -205,6 +205,17 @@ struct Builder {
         }
     }
 
+    /* outward rounding of a box plane to single precision */
+    static float float_down(double v) {
+        float f = (float)v;
+        if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+        return std::nextafterf(f, -INFINITY);
+    }
+    static float float_up(double v) {
+        float f = (float)v;
+        if ((double)f < v) f = std::nextafterf(f, INFINITY);
+        return std::nextafterf(f, INFINITY);
+    }
     static double half_area(const Box& b) {
         const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
         return x * y + y * z + z * x;
@@ -283,8 +294,8 @@ struct Builder {
         const int r = build_tree(refs, mid, hi, ref_base, depth + 1, max_depth, br);
         FBvh node{};
         for (int c = 0; c < 3; ++c) {
-            node.lmin[c] = bl.lo[c], node.lmax[c] = bl.hi[c];
-            node.rmin[c] = br.lo[c], node.rmax[c] = br.hi[c];
+            node.lmin[c] = float_down(bl.lo[c]), node.lmax[c] = float_up(bl.hi[c]);
+            node.rmin[c] = float_down(br.lo[c]), node.rmax[c] = float_up(br.hi[c]);
         }
         node.left = l, node.right = r;
         out.bvh[me] = node;
@@ -315,6 +326,9 @@ struct Builder {
                 int depth = 0;
                 Box all;
                 I.bvh_root = build_tree(refs, 0, (int)refs.size(), I.ref_first, 1, depth, all);
+                double bound = 0;
+                for (int c = 0; c < 3; ++c) bound = std::max(bound, std::max(std::fabs(all.lo[c]), std::fabs(all.hi[c])));
+                I.bound = float_up(bound);
                 stack = std::max(stack, depth + 2);
             }
             Box local;

@@ -196,7 +196,8 @@ struct FInst {
     int32_t xf_first, n_xf;  /* transform ops, outermost first */
     int32_t ref_first, n_ref;
     int32_t bvh_root;        /* -1: scan the references linearly */
-    int32_t pad[3];
+    float bound;             /* box tree: largest |coordinate| of any of its boxes (instance frame) */
+    int32_t pad[2];
 };
 struct FXf {
     int32_t type; /* RTR_NODE_TRANSLATE (f = offset) or RTR_NODE_ROTATE_Y (f[0] = sin, f[1] = cos) */
@@ -210,11 +211,12 @@ struct FRef {
     int32_t pad;        /* host side: visiting order (copied into fprim[].reserved) */
 };
 /* One INNER node of an instance's box tree: the boxes of both children next to their links, so a
- * traversal step costs one record fetch.  A link >= 0 is another inner node; a negative link is a
+ * traversal step costs one 64-byte record.  A link >= 0 is another inner node; a negative link is a
  * leaf, -1 - ((first_reference << 3) | (count - 1)), count <= 8.  The tree is built with a binned
- * surface-area heuristic (rt_compile.h); any tree is valid, the boxes only prune. */
+ * surface-area heuristic (rt_compile.h).  Boxes are SINGLE precision, rounded outward: they only
+ * prune, the primitive tests behind them stay in double and exact (see struct BoxRay). */
 struct FBvh {
-    double lmin[3], lmax[3], rmin[3], rmax[3];
+    float lmin[3], lmax[3], rmin[3], rmax[3];
     int32_t left, right;
     int32_t pad[2];
 };
@@ -564,12 +566,64 @@ RT_DEV bool box_enter(const double* bmin, const double* bmax, V3 o, V3 inv, Real
     return lo <= hi; /* NaNs (0 * inf) drop out of fmin/fmax, which keeps the test conservative */
 }
 
+/* Conservative single-precision slab test for the box trees.  For axis k the entry / exit
+ * parameters are fma(plane_k, idir_k, c_k) with idir = float(1/d), c_near = float(-o/d - slack),
+ * c_far = float(-o/d + slack) and slack = 2^-21 |1/d| (|o| + bound): that covers the rounding of
+ * idir (2^-24 |plane/d|), of c (2^-24 |o/d|) and of the fma itself with a factor 4 to spare, so the
+ * computed interval always CONTAINS the exact one and no box the double-precision ray enters is
+ * ever skipped; it widens a box by ~5e-7 of the scene size.  An axis the ray is (nearly) parallel to
+ * (|1/d| >= 1e30, inf or NaN) is switched off (idir = 0, c = -/+inf), which is conservative too. */
+struct BoxRay {
+    float idx, idy, idz;
+    float cnx, cny, cnz;
+    float cfx, cfy, cfz;
+    bool sx, sy, sz; /* direction negative: the box's max plane is the near one */
+};
+RT_DEV void boxray_axis(Real o, Real d, float bound, float& idir, float& cn, float& cf, bool& neg_dir) {
+    const Real inv = 1.0 / d;
+    const Real ainv = __builtin_fabs(inv);
+    const bool usable = ainv < 1e30; /* false for inf and NaN as well */
+    const Real slack = 0x1p-21 * ainv * (__builtin_fabs(o) + (Real)bound);
+    const Real mid = -o * inv;
+    idir = usable ? (float)inv : 0.0f;
+    cn = usable ? (float)(mid - slack) : -__builtin_huge_valf();
+    cf = usable ? (float)(mid + slack) : __builtin_huge_valf();
+    neg_dir = inv < 0;
+}
+RT_DEV BoxRay boxray_make(V3 o, V3 d, float bound) {
+    BoxRay r;
+    boxray_axis(o.x, d.x, bound, r.idx, r.cnx, r.cfx, r.sx);
+    boxray_axis(o.y, d.y, bound, r.idy, r.cny, r.cfy, r.sy);
+    boxray_axis(o.z, d.z, bound, r.idz, r.cnz, r.cfz, r.sz);
+    return r;
+}
+/* round a double bound of the ray interval to float, outward */
+RT_DEV float float_below(Real t) {
+    const float f = (float)t;
+    return __builtin_fmaf(-__builtin_fabsf(f), 0x1p-23f, f);
+}
+RT_DEV float float_above(Real t) {
+    const float f = (float)t;
+    return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f);
+}
+RT_DEV bool boxray_hit(const BoxRay& r, const float* bmin, const float* bmax, float tmin, float tmax, float& tnear) {
+    const float nx = r.sx ? bmax[0] : bmin[0], fx = r.sx ? bmin[0] : bmax[0];
+    const float ny = r.sy ? bmax[1] : bmin[1], fy = r.sy ? bmin[1] : bmax[1];
+    const float nz = r.sz ? bmax[2] : bmin[2], fz = r.sz ? bmin[2] : bmax[2];
+    /* fmaxf / fminf drop NaNs (0 * inf): such an axis does not constrain the interval */
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx, r.idx, r.cnx), __builtin_fmaf(ny, r.idy, r.cny)),
+                                     __builtin_fmaxf(__builtin_fmaf(nz, r.idz, r.cnz), tmin));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(fx, r.idx, r.cfx), __builtin_fmaf(fy, r.idy, r.cfy)),
+                                     __builtin_fminf(__builtin_fmaf(fz, r.idz, r.cfz), tmax));
+    tnear = tn;
+    return tn <= tf;
+}
+
 /* One reference of an instance against the ray in the instance frame.  (Exact ties in t, e.g. the
  * coplanar side faces of adjacent boxes in scene 9, are won by whichever primitive is tested
  * last; in the reference that is decided by 1-ulp noise of its BVH box tests, so neither order
  * can be called "the" reference behaviour.  Such faces share material and normal there.) */
-RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
-    const rtr_node n = ld_const(sc.fprim, ref);
+RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
     const int type = n.type;
     if (type >= RTR_NODE_XY_RECT) {
         Real a, b;
@@ -579,6 +633,10 @@ RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real 
     Real radius;
     sphere_geom(n, type, time, center, radius);
     return sphere_hit_t(center, radius, o, d, tmin, tmax, t);
+}
+RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
+    const rtr_node n = ld_const(sc.fprim, ref);
+    return fast_prim_hit(n, o, d, time, tmin, tmax, t);
 }
 
 /* Closest hit (ANY = false) or first hit found (ANY = true: shadow rays only need existence).
@@ -596,7 +654,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
     hit_inst = -1;
     for (int ii = inst_first; ii < inst_first + n_inst; ++ii) {
         const FInst I = ld_const(sc.finst, ii);
-        V3 lo = o, ld = d, linv = inv;
+        V3 lo = o, ld = d;
         const int n_xf = I.n_xf;
         if (n_xf) {
             if (use_boxes) {
@@ -608,7 +666,6 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                 wrapper_enter(x.type, x.f, lo, ld);
             }
         }
-        if (I.bvh_root >= 0 && (n_xf || !use_boxes)) linv = mk(1.0 / ld.x, 1.0 / ld.y, 1.0 / ld.z);
         if (I.bvh_root < 0) {
             const int r0 = I.ref_first, r1 = r0 + I.n_ref;
             for (int r = r0; r < r1; ++r) {
@@ -623,14 +680,17 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
         } else {
             /* while-while traversal: every lane first walks down to its next leaf, then the wave
              * tests leaf primitives together (the expensive, exact part) */
+            const BoxRay br = boxray_make(lo, ld, I.bound);
+            const float tmin_f = float_below(tmin);
+            float tmax_f = float_above(tmax);
             int sp = sp0;
             int node = I.bvh_root;
             while (true) {
                 while (node >= 0) {
                     const FBvh& b = sc.fbvh[node];
-                    Real tl, tr;
-                    const bool hl = box_enter(b.lmin, b.lmax, lo, linv, tmin, tmax, tl);
-                    const bool hr = box_enter(b.rmin, b.rmax, lo, linv, tmin, tmax, tr);
+                    float tl, tr;
+                    const bool hl = boxray_hit(br, b.lmin, b.lmax, tmin_f, tmax_f, tl);
+                    const bool hr = boxray_hit(br, b.rmin, b.rmax, tmin_f, tmax_f, tr);
                     const int cl = b.left, cr = b.right;
                     if (hl && hr) { /* nearer child first */
                         const bool left_first = tl <= tr;
@@ -651,6 +711,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                     Real t;
                     if (fast_ref_hit(sc, r, lo, ld, time, tmin, tmax, t)) {
                         tmax = t;
+                        tmax_f = float_above(t);
                         hit_ref = r;
                         hit_inst = ii;
                         if (ANY) return true;

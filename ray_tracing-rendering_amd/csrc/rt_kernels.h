@@ -49,6 +49,9 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
 #ifndef RTR_MEGA_WAVES
 #define RTR_MEGA_WAVES 4 /* min waves per SIMD the register allocator must leave room for */
 #endif
+#ifndef RTR_PROGRAM_WAVES
+#define RTR_PROGRAM_WAVES 3 /* media scenes are traversal-latency bound: a third wave pays for the spills it causes */
+#endif
 
 /* Per-lane path state that the ray casts do not touch lives in LDS between shading steps
  * ("parked"), so it does not occupy VGPRs across the traversal loops: throughput, radiance of
@@ -67,7 +70,7 @@ struct Park {
 enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_CONTRIB = 9, PK_PDF = 12, PK_SWI = 13, PK_STMAX = 16, PK_NCLOSEST = 17, PK_NSHADOW = 18 };
 
 template <int INTEG, int TRAV, int MS>
-__global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES : 2)
+__global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES : (TRAV == RT_TRAV_PROGRAM ? RTR_PROGRAM_WAVES : 2))
     k_mega(const DScene* __restrict__ scp, const RenderK P, const int stack_words) {
     extern __shared__ int lds_stack[];
     const DScene& sc = *scp;
@@ -135,13 +138,22 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
         pk.set(PK_NCLOSEST, 0.0);
         pk.set(PK_NSHADOW, 0.0);
         if (!done) begin_sample();
+#ifdef RTR_PHASE_CLOCKS
+        long long clk_closest = 0, clk_shade = 0, clk_shadow = 0, clk_other = 0, clk_t = wall_clock64();
+#define RTR_CLK(acc) do { const long long now_ = wall_clock64(); acc += now_ - clk_t; clk_t = now_; } while (0)
+#else
+#define RTR_CLK(acc) do { } while (0)
+#endif
         while (!done) {
             bool pending = false, ended = false;
+            RTR_CLK(clk_other);
             {
                 Hit rec;
                 rec.u = 0, rec.v = 0;
                 pk.set(PK_NCLOSEST, pk.get(PK_NCLOSEST) + 1.0);
-                if (!cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st)) {
+                const bool hit_any = cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st);
+                RTR_CLK(clk_closest);
+                if (!hit_any) {
                     pk.set3(PK_L, add(pk.get3(PK_L), miss_radiance<INTEG>(sc, pk.get3(PK_THR), ps.ro, ps.rd, ps.depth,
                                                                           ps.specular_bounce, pk.get(PK_PDF))));
                     ended = true;
@@ -188,11 +200,13 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                     ended = !go || ++ps.depth >= P.max_depth;
                 }
             }
+            RTR_CLK(clk_shade);
             if (pending) { /* mis_path_integrator.h:210-213, origin = the hit point = ps.ro */
                 pk.set(PK_NSHADOW, pk.get(PK_NSHADOW) + 1.0);
                 if (!cast_shadow<TRAV>(sc, ps.ro, pk.get3(PK_SWI), pk.get(PK_STMAX), rng, st))
                     pk.set3(PK_L, add(pk.get3(PK_L), pk.get3(PK_CONTRIB)));
             }
+            RTR_CLK(clk_shadow);
             if (ended) {
                 pk.set3(PK_ACC, add(pk.get3(PK_ACC), pk.get3(PK_L))); /* renderer.h:77-78 */
                 ++n_samples;
@@ -203,6 +217,14 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
         }
         cnt.closest = (uint32_t)pk.get(PK_NCLOSEST);
         cnt.shadow = (uint32_t)pk.get(PK_NSHADOW);
+#ifdef RTR_PHASE_CLOCKS
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&P.stats[3], (unsigned long long)clk_closest);
+            atomicAdd(&P.stats[4], (unsigned long long)clk_shade);
+            atomicAdd(&P.stats[5], (unsigned long long)clk_shadow);
+            atomicAdd(&P.stats[6], (unsigned long long)clk_other);
+        }
+#endif
     }
     const V3 acc = pk.get3(PK_ACC);
     double* out = P.partial + (size_t)blockIdx.x * 3 * RTR_BLOCK + threadIdx.x;

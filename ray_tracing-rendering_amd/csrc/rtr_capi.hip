@@ -380,8 +380,12 @@ int finish_stats(rtr_context* c) {
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    unsigned long long h[3] = {0, 0, 0};
+    unsigned long long h[8] = {0};
     HIPCHK(c, hipMemcpy(h, c->b_stats.p, sizeof h, hipMemcpyDeviceToHost));
+#ifdef RTR_PHASE_CLOCKS
+    std::fprintf(stderr, "[phase clocks] closest %.3e  shade %.3e  shadow %.3e  other %.3e (wave cycles)\n", (double)h[3],
+                 (double)h[4], (double)h[5], (double)h[6]);
+#endif
     c->stats.samples = h[0];
     c->stats.closest_segments = h[1];
     c->stats.shadow_segments = h[2];
@@ -453,7 +457,7 @@ int rtr_create(int device_ordinal, rtr_context** out_ctx) {
     CREATE_CHK(hipEventCreate(&c->ev1));
 #undef CREATE_CHK
     c->stream = c->own_stream;
-    int rc = ensure(c, c->b_stats, 3 * sizeof(unsigned long long));
+    int rc = ensure(c, c->b_stats, 8 * sizeof(unsigned long long));
     if (!rc) rc = ensure(c, c->b_cancel, sizeof(int));
     if (!rc && hipMemset(c->b_cancel.p, 0, sizeof(int)) != hipSuccess) rc = RTR_ERR_DEVICE;
     if (rc) {
@@ -619,7 +623,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     P.tile_ids = static_cast<const int*>(c->b_tiles.p);
     P.stats = static_cast<unsigned long long*>(c->b_stats.p);
     P.cancel = static_cast<const int*>(c->b_cancel.p);
-    HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
 
     if ((rc = ensure(c, c->b_partial, (size_t)P.n_tiles * chunks * 3 * RTR_BLOCK * sizeof(double)))) return rc;
     P.partial = static_cast<double*>(c->b_partial.p);

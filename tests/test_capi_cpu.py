@@ -52,7 +52,10 @@ def test_validate_golden_scenes(sid, words, media):
     if sid == 23:
         assert (info["fast_instances"], info["fast_refs"]) == (1, 6)
     if media:  # the box field, and the BVH branch holding the sphere cloud + 2 spheres, are compiled
-        assert info["compiled_subtrees"] == 2 and info["fast_refs"] == 2400 + 1000 + 2
+        # hybrid walk: 2 compiled subtrees (3402 references); the step program holds the same geometry
+        # again plus the 8 small objects / medium boundaries around it
+        assert info["compiled_subtrees"] == 2 and info["fast_refs"] == 2 * (2400 + 1000 + 2) + 8
+        assert info["program_steps"] == 5
 
 
 def _mutated(sid, fn):
