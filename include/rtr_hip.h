@@ -117,7 +117,8 @@ typedef struct rtr_perlin {
     int32_t perm_z[256];
 } rtr_perlin; /* 9216 bytes */
 
-/* 8-bit RGB images for image_texture (materials/texture.h:96-107) */
+/* 8-bit RGB images for image_texture (materials/texture.h:96-107); image_bytes also holds the
+ * float texels and sampling tables of RTR_LIGHT_ENV_MAP lights */
 typedef struct rtr_image {
     int32_t width;
     int32_t height;
@@ -132,7 +133,14 @@ typedef enum rtr_light_type {
     RTR_LIGHT_DIRECTIONAL = 3, /* DirectionalLight lighting/directional_light.h:7-31: f[0..2]=unit direction f[3..5]=radiance */
     RTR_LIGHT_ENV_UNIFORM = 4, /* EnvironmentLight whose map file is missing (lighting/environmental_light.h:126-131,
                                   187-192,251-252,293-294): uniform white sky, sampled with random_unit_vector() */
-    RTR_LIGHT_TYPE_COUNT = 5
+    RTR_LIGHT_ENV_MAP = 5,     /* EnvironmentLight with its HDR map (lighting/environmental_light.h:120-374):
+                                  f[0]=width f[1]=height f[2]=is_light_probe (square map = angular probe, :137-140)
+                                  f[3]=byte offset in rtr_scene_desc.image_bytes of the float32 RGB texels as stbi_loadf
+                                       returns them (row 0 first, 3*width floats per row; multiple of 4)
+                                  f[4]=byte offset (multiple of 8) of the float64 sampling tables of Distribution2D
+                                       (:60-117): per map row v {func[width], cdf[width+1], func_int}, then the
+                                       marginal {func[height], cdf[height+1], func_int} */
+    RTR_LIGHT_TYPE_COUNT = 6
 } rtr_light_type;
 
 typedef struct rtr_light {

@@ -127,6 +127,40 @@ def main():
         cmd, info = run("render", 4, 1, 64, 16, 1, SCENE_SEED, os.path.join(GOLD, name), 8, cwd=td)
         note(name, cmd, info, scene=4, integrator=1, width=64, height=info["height"], spp=16, seed=1)
 
+    # EnvironmentLight WITH its HDR map.  The reference's .hdr assets do not ship either,
+    # so two small synthetic Radiance RGBE pictures (flat scanlines, which stb_image's stbi_loadf
+    # accepts) are written under the names scenes 24 / 26 ask for: a 32x16 equirectangular map with
+    # a bright "sun" and a 16x16 square map, which the reference treats as an angular light probe.
+    def write_hdr(path, w, h, sun):
+        px = bytearray()
+        for j in range(h):
+            for i in range(w):
+                e = 128 + (i + 2 * j) % 3
+                if (i, j) in sun:
+                    e = 135
+                px += bytes((40 + (i * 7 + j * 3) % 200, 30 + (i * 5 + j * 11) % 200, 20 + (i * 3 + j * 13) % 220, e))
+        with open(path, "wb") as f:
+            f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(px))
+
+    with tempfile.TemporaryDirectory() as td:
+        write_hdr(os.path.join(td, "brown_photostudio_02_4k.hdr"), 32, 16, {(20, 4), (21, 4), (20, 5)})
+        write_hdr(os.path.join(td, "rnl_probe.hdr"), 16, 16, {(11, 5), (4, 9)})
+        for sid, what in ((24, "synthetic 32x16 RGBE as brown_photostudio_02_4k.hdr (equirectangular)"),
+                          (26, "synthetic 16x16 RGBE as rnl_probe.hdr (angular probe)")):
+            name = "scene%02d.rtrs" % sid
+            cmd, info = run("dump-scene", sid, SCENE_SEED, os.path.join(GOLD, name), cwd=td)
+            note(name, cmd, info, raw_sha256=sha(os.path.join(GOLD, name)), asset=what)
+            name = "lights_scene%02d.bin" % sid
+            cmd, info = run("lights", sid, SCENE_SEED, 256, 99 + sid, os.path.join(GOLD, name), cwd=td)
+            note(name, cmd, info, scene=sid)
+            for integ in (4, 3):
+                name = "li_scene%02d_i%d.bin" % (sid, integ)
+                cmd, info = run("li", sid, integ, 64, 16, 1, SCENE_SEED, 768, os.path.join(GOLD, name), cwd=td)
+                note(name, cmd, info, scene=sid, integrator=integ, width=64, spp=16, seed=1)
+                name = "img_scene%02d_i%d_64_spp16.f64" % (sid, integ)
+                cmd, info = run("render", sid, integ, 64, 16, 1, SCENE_SEED, os.path.join(GOLD, name), 8, cwd=td)
+                note(name, cmd, info, scene=sid, integrator=integ, width=64, height=info["height"], spp=16, seed=1)
+
     # one mid-size image of the headline config's scene
     name = "img_scene21_i4_128_spp32.f64"
     cmd, info = run("render", 21, 4, 128, 32, 7, SCENE_SEED, os.path.join(GOLD, name), 8)

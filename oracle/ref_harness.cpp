@@ -280,8 +280,33 @@ struct Flattener {
             put3(r.f, dl->direction);
             put3(r.f + 3, dl->L);
         } else if (auto el = dynamic_cast<const EnvironmentLight*>(l)) {
-            if (el->width != 0 || el->height != 0) die("EnvironmentLight with a loaded map is not flattened yet");
-            r.type = RTR_LIGHT_ENV_UNIFORM;
+            if (el->width == 0 || el->height == 0) {
+                r.type = RTR_LIGHT_ENV_UNIFORM;
+            } else { /* texels + Distribution2D tables into image_bytes (layout: rtr_hip.h, RTR_LIGHT_ENV_MAP) */
+                r.type = RTR_LIGHT_ENV_MAP;
+                const int w = el->width, h = el->height;
+                auto& blob = out.image_bytes;
+                auto append = [&blob](const void* p, size_t n) {
+                    const uint8_t* b = static_cast<const uint8_t*>(p);
+                    blob.insert(blob.end(), b, b + n);
+                };
+                while (blob.size() % 8) blob.push_back(0);
+                r.f[0] = w, r.f[1] = h, r.f[2] = el->is_light_probe ? 1.0 : 0.0;
+                r.f[3] = (double)blob.size();
+                if (el->hdr_data.size() != (size_t)w * h * 3) die("unexpected hdr_data size");
+                append(el->hdr_data.data(), el->hdr_data.size() * sizeof(float));
+                while (blob.size() % 8) blob.push_back(0);
+                r.f[4] = (double)blob.size();
+                auto put_dist = [&](const Distribution1D& d, int n) {
+                    if ((int)d.func.size() != n || (int)d.cdf.size() != n + 1) die("unexpected Distribution1D size");
+                    append(d.func.data(), n * sizeof(double));
+                    append(d.cdf.data(), (n + 1) * sizeof(double));
+                    append(&d.func_int, sizeof(double));
+                };
+                if ((int)el->distribution.conditional.size() != h) die("unexpected Distribution2D size");
+                for (int v = 0; v < h; ++v) put_dist(el->distribution.conditional[v], w);
+                put_dist(el->distribution.marginal, h);
+            }
         } else {
             die("unsupported light class in reference scene");
         }

@@ -657,8 +657,135 @@ struct LightSample {
     double pdf, dist;
     bool is_delta;
 };
-LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy, Rng& g) {
+/* ---- lighting/environmental_light.h: the HDR map and its Distribution2D ---------------- */
+struct EnvMap {
+    int w, h;
+    bool probe;
+    const float* texels;
+    const double* tables;
+    /* Distribution1D of map row v (v == h: the marginal): func[n], cdf[n+1], func_int */
+    const double* dist(int v, int& n) const {
+        n = v < h ? w : h;
+        return tables + (v < h ? (size_t)v * (2 * w + 2) : (size_t)h * (2 * w + 2));
+    }
+};
+inline EnvMap env_map(const rtr_light& l, const uint8_t* blob) {
+    EnvMap m;
+    m.w = (int)l.f[0], m.h = (int)l.f[1], m.probe = l.f[2] != 0;
+    m.texels = reinterpret_cast<const float*>(blob + (size_t)l.f[3]);
+    m.tables = reinterpret_cast<const double*>(blob + (size_t)l.f[4]);
+    return m;
+}
+/* Distribution1D::sample (:30-45) */
+double dist1d_sample(const double* d, int n, double u, double& pdf_out, int& offset) {
+    const double *func = d, *cdf = d + n, func_int = d[2 * n + 1];
+    int lo = 0, hi = n + 1; /* std::lower_bound over cdf[0 .. n] */
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        if (cdf[mid] < u)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    offset = std::max(0, lo - 1);
+    offset = std::min(offset, n - 1);
+    double du = u - cdf[offset];
+    if (cdf[offset + 1] - cdf[offset] > 0) du /= (cdf[offset + 1] - cdf[offset]);
+    pdf_out = (func_int > 0) ? func[offset] / func_int : 0;
+    return (offset + du) / n;
+}
+/* Distribution1D::pdf (:47-49) */
+double dist1d_pdf(const double* d, int n, int index) {
+    const double func_int = d[2 * n + 1];
+    return (func_int > 0) ? d[index] / (func_int * n) : 0;
+}
+/* EnvironmentLight::get_pixel / Le (:226-289) */
+V3 env_pixel(const EnvMap& m, int i, int j) {
+    if (i < 0) i += m.w;
+    if (i >= m.w) i -= m.w;
+    if (j < 0) j = 0;
+    if (j >= m.h) j = m.h - 1;
+    const float* t = m.texels + 3 * ((size_t)j * m.w + i);
+    return mk(t[0], t[1], t[2]);
+}
+V3 env_Le(const EnvMap& m, V3 direction) {
+    V3 unit_dir = unit(direction);
+    double u, v;
+    if (m.probe) {
+        double d = std::sqrt(unit_dir.x * unit_dir.x + unit_dir.y * unit_dir.y);
+        double r_coord = (d > 0) ? (1.0 / kPi) * std::acos(unit_dir.z) / d : 0.0;
+        u = (unit_dir.x * r_coord + 1.0) * 0.5;
+        v = (unit_dir.y * r_coord + 1.0) * 0.5;
+        v = 1.0 - v;
+    } else {
+        double theta = std::acos(unit_dir.y);
+        double phi = std::atan2(-unit_dir.z, unit_dir.x) + kPi;
+        u = phi / (2 * kPi);
+        v = theta / kPi;
+    }
+    double u_img = u * m.w - 0.5;
+    double v_img = v * m.h - 0.5;
+    int i0 = static_cast<int>(std::floor(u_img));
+    int j0 = static_cast<int>(std::floor(v_img));
+    double du = u_img - i0;
+    double dv = v_img - j0;
+    V3 c00 = env_pixel(m, i0, j0), c10 = env_pixel(m, i0 + 1, j0);
+    V3 c01 = env_pixel(m, i0, j0 + 1), c11 = env_pixel(m, i0 + 1, j0 + 1);
+    V3 c0 = add(scl(1 - du, c00), scl(du, c10));
+    V3 c1 = add(scl(1 - du, c01), scl(du, c11));
+    return add(scl(1 - dv, c0), scl(dv, c1));
+}
+
+LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy, Rng& g, const uint8_t* blob) {
     LightSample s;
+    if (l.type == RTR_LIGHT_ENV_MAP) { /* environmental_light.h:182-246 */
+        const EnvMap m = env_map(l, blob);
+        s.dist = kInf;
+        s.is_delta = false;
+        s.wi = mk(0, 0, 0); /* LightSample has no initialisers (light.h:7-13); callers test pdf / Li first */
+        double pdfs[2];
+        int v_idx, u_idx, n;
+        const double* marg = m.dist(m.h, n);
+        double v = dist1d_sample(marg, n, uy, pdfs[1], v_idx);
+        const double* cond = m.dist(v_idx, n);
+        double u = dist1d_sample(cond, n, ux, pdfs[0], u_idx);
+        double map_pdf = pdfs[0] * pdfs[1];
+        if (map_pdf == 0) {
+            s.Li = mk(0, 0, 0);
+            s.pdf = 0;
+            return s;
+        }
+        double phi, theta;
+        if (m.probe) {
+            double uc = u * 2.0 - 1.0;
+            double vc = (1.0 - v) * 2.0 - 1.0;
+            double r = std::sqrt(uc * uc + vc * vc);
+            if (r > 1.0) {
+                s.Li = mk(0, 0, 0);
+                s.pdf = 0;
+                return s;
+            }
+            theta = kPi * r;
+            phi = std::atan2(vc, uc);
+            double sin_theta = std::sin(theta);
+            s.wi = mk(sin_theta * std::cos(phi), sin_theta * std::sin(phi), std::cos(theta));
+        } else {
+            phi = u * 2 * kPi - kPi;
+            theta = v * kPi;
+            double sin_theta = std::sin(theta);
+            double cos_theta = std::cos(theta);
+            s.wi = mk(sin_theta * std::cos(phi), cos_theta, -sin_theta * std::sin(phi));
+        }
+        double sin_theta = std::sin(theta);
+        if (sin_theta < 1e-6) {
+            s.Li = mk(0, 0, 0);
+            s.pdf = 0;
+            return s;
+        }
+        s.pdf = map_pdf * m.w * m.h / (2.0 * kPi * kPi * sin_theta);
+        s.Li = env_Le(m, s.wi);
+        return s;
+    }
     if (l.type == RTR_LIGHT_ENV_UNIFORM) { /* environmental_light.h:182-192: no map loaded */
         s.dist = kInf;
         s.is_delta = false;
@@ -718,8 +845,36 @@ LightSample light_sample(const rtr_light& l, V3 p, double ux, double uy, Rng& g)
     s.pdf = dist_sq / (area * cos_theta);
     return s;
 }
-double light_pdf(const rtr_light& l, V3 origin, V3 direction) { /* quad_light.h:50-77 */
+double light_pdf(const rtr_light& l, V3 origin, V3 direction, const uint8_t* blob) { /* quad_light.h:50-77 */
     if (l.type == RTR_LIGHT_ENV_UNIFORM) return 1.0 / (4.0 * kPi); /* environmental_light.h:293-294 */
+    if (l.type == RTR_LIGHT_ENV_MAP) { /* environmental_light.h:291-331 */
+        const EnvMap m = env_map(l, blob);
+        V3 unit_dir = unit(direction);
+        double u, v, theta;
+        if (m.probe) {
+            double d = std::sqrt(unit_dir.x * unit_dir.x + unit_dir.y * unit_dir.y);
+            double r_coord = (d > 0) ? (1.0 / kPi) * std::acos(unit_dir.z) / d : 0.0;
+            u = (unit_dir.x * r_coord + 1.0) * 0.5;
+            v = (unit_dir.y * r_coord + 1.0) * 0.5;
+            v = 1.0 - v;
+            theta = std::acos(unit_dir.z);
+        } else {
+            theta = std::acos(unit_dir.y);
+            double phi = std::atan2(-unit_dir.z, unit_dir.x) + kPi;
+            u = phi / (2 * kPi);
+            v = theta / kPi;
+        }
+        double sin_theta = std::sin(theta);
+        if (sin_theta < 1e-6) return 0;
+        int u_idx = (int)clampd(int(u * m.w), 0, m.w - 1);
+        int v_idx = (int)clampd(int(v * m.h), 0, m.h - 1);
+        int n;
+        const double* cond = m.dist(v_idx, n);
+        double pu = dist1d_pdf(cond, n, u_idx);
+        const double* marg = m.dist(m.h, n);
+        double map_pdf = pu * dist1d_pdf(marg, n, v_idx);
+        return map_pdf * m.w * m.h / (2.0 * kPi * kPi * sin_theta);
+    }
     if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf base (light.h:26-28): delta lights */
     V3 Q = ld(l.f), U = ld(l.f + 3), Vv = ld(l.f + 6), normal = ld(l.f + 12);
     double area = l.f[15];
@@ -771,20 +926,25 @@ double compute_light_pdf(const Scene& sc, const Ray& current_ray) { /* :173-188 
     double total_pdf = 0.0;
     double light_select_pdf = 1.0 / sc.d->n_lights;
     for (int k = 0; k < sc.d->n_lights; ++k)
-        total_pdf += light_pdf(sc.d->lights[k], current_ray.o, current_ray.d) * light_select_pdf;
+        total_pdf += light_pdf(sc.d->lights[k], current_ray.o, current_ray.d, sc.d->image_bytes) * light_select_pdf;
     return total_pdf;
 }
 
 /* radiance of the infinite lights seen by a ray that left the scene (environmental_light.h:226-229:
  * Le = (1,1,1) without a map); `found` = some light is infinite */
-V3 env_radiance(const Scene& sc, bool& found) {
+V3 env_radiance(const Scene& sc, V3 direction, bool& found) {
     V3 env = mk(0, 0, 0);
     found = false;
-    for (int k = 0; k < sc.d->n_lights; ++k)
-        if (sc.d->lights[k].type == RTR_LIGHT_ENV_UNIFORM) {
+    for (int k = 0; k < sc.d->n_lights; ++k) {
+        const rtr_light& l = sc.d->lights[k];
+        if (l.type == RTR_LIGHT_ENV_UNIFORM) {
             env = add(env, mk(1, 1, 1));
             found = true;
+        } else if (l.type == RTR_LIGHT_ENV_MAP) {
+            env = add(env, env_Le(env_map(l, sc.d->image_bytes), direction));
+            found = true;
         }
+    }
     return env;
 }
 
@@ -798,7 +958,7 @@ V3 sample_lights_mis(const Scene& sc, const Rec& rec, V3 wo, Rng& g, Counters& c
     /* vec2 u(random_double(), random_double()): u.y takes the first draw (g++ order) */
     double uy = g.next();
     double ux = g.next();
-    LightSample ls = light_sample(light, rec.p, ux, uy, g);
+    LightSample ls = light_sample(light, rec.p, ux, uy, g, sc.d->image_bytes);
     if (ls.pdf > 0 && len2(ls.Li) > 0) {
         Ray shadow_ray = make_ray(rec.p, ls.wi, 0);
         Rec shadow_rec;
@@ -834,7 +994,7 @@ V3 li_mis(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g, Co
         ++cnt.closest;
         if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) { /* :37-67 */
             bool found_env;
-            V3 env_L = env_radiance(sc, found_env);
+            V3 env_L = env_radiance(sc, current_ray.d, found_env);
             if (!found_env) {
                 L = add(L, mul(throughput, background));
             } else if (depth == 0 || specular_bounce) {
@@ -988,7 +1148,7 @@ V3 sample_lights_direct(const Scene& sc, const Rec& rec, V3 wo, Rng& g, Counters
     double light_pdf_sel = 1.0 / n_lights;
     double uy = g.next();
     double ux = g.next();
-    LightSample ls = light_sample(light, rec.p, ux, uy, g);
+    LightSample ls = light_sample(light, rec.p, ux, uy, g, sc.d->image_bytes);
     if (ls.pdf > 0 && len2(ls.Li) > 0) {
         Ray shadow_ray = make_ray(rec.p, ls.wi, 0);
         Rec shadow_rec;
@@ -1023,11 +1183,16 @@ V3 li_direct(const Scene& sc, const Ray& r, int max_depth, int rr_start, Rng& g,
         ++cnt.closest;
         if (!hit_node(sc, sc.d->root, current_ray, 0.001, kInf, rec, g)) { /* :41-54 */
             bool found_env = false;
-            for (int k = 0; k < sc.d->n_lights; ++k)
-                if (sc.d->lights[k].type == RTR_LIGHT_ENV_UNIFORM) {
+            for (int k = 0; k < sc.d->n_lights; ++k) {
+                const rtr_light& l = sc.d->lights[k];
+                if (l.type == RTR_LIGHT_ENV_UNIFORM) {
                     L = add(L, mul(throughput, mk(1, 1, 1)));
                     found_env = true;
+                } else if (l.type == RTR_LIGHT_ENV_MAP) {
+                    L = add(L, mul(throughput, env_Le(env_map(l, sc.d->image_bytes), current_ray.d)));
+                    found_env = true;
                 }
+            }
             if (!found_env) L = add(L, mul(throughput, background));
             break;
         }
@@ -1222,11 +1387,11 @@ int rto_lights(const rtr_scene_desc* scene, rtr_light_record* recs, int64_t n) {
         if (o.light < 0 || o.light >= scene->n_lights) return RTR_ERR_INVALID;
         const rtr_light& l = scene->lights[o.light];
         Rng g{0x2545F491u}; /* the uniform environment light draws its direction itself */
-        LightSample s = light_sample(l, ld(o.p), o.u[0], o.u[1], g);
+        LightSample s = light_sample(l, ld(o.p), o.u[0], o.u[1], g, scene->image_bytes);
         o.Li[0] = s.Li.x, o.Li[1] = s.Li.y, o.Li[2] = s.Li.z;
         o.wi[0] = s.wi.x, o.wi[1] = s.wi.y, o.wi[2] = s.wi.z;
         o.pdf = s.pdf, o.dist = s.dist, o.is_delta = s.is_delta, o.pad2 = 0;
-        o.pdf_dir = light_pdf(l, ld(o.p), ld(o.dir));
+        o.pdf_dir = light_pdf(l, ld(o.p), ld(o.dir), scene->image_bytes);
     }
     return RTR_OK;
 }

@@ -20,7 +20,7 @@ RTR_ERR_NOMEM = -6
  NODE_MOVING_SPHERE, NODE_XY_RECT, NODE_XZ_RECT, NODE_YZ_RECT) = range(11)
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_PBR, MAT_ISOTROPIC = range(6)
 TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(4)
-LIGHT_QUAD, LIGHT_POINT, LIGHT_SPOT, LIGHT_DIRECTIONAL, LIGHT_ENV_UNIFORM = 0, 1, 2, 3, 4
+LIGHT_QUAD, LIGHT_POINT, LIGHT_SPOT, LIGHT_DIRECTIONAL, LIGHT_ENV_UNIFORM, LIGHT_ENV_MAP = 0, 1, 2, 3, 4, 5
 
 INTEGRATOR_PATH, INTEGRATOR_RR, INTEGRATOR_PBR, INTEGRATOR_NEE, INTEGRATOR_MIS = 0, 1, 2, 3, 4
 PIPELINE_AUTO, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1, 2

@@ -1221,9 +1221,147 @@ struct LightSample {
     Real pdf, dist;
     bool is_delta;
 };
-RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy, uint32_t& rng) {
+/* ---- lighting/environmental_light.h: HDR map + Distribution2D (layout: rtr_hip.h, RTR_LIGHT_ENV_MAP) ---- */
+struct EnvMap {
+    int w, h;
+    bool probe;
+    const float* texels;
+    const double* tables;
+    /* Distribution1D of map row v (v == h: the marginal): func[n], cdf[n + 1], func_int */
+    RT_DEV const double* dist(int v, int& n) const {
+        n = v < h ? w : h;
+        return tables + (v < h ? (size_t)v * (2 * w + 2) : (size_t)h * (2 * w + 2));
+    }
+};
+RT_DEV EnvMap env_map(const rtr_light& l, const uint8_t* blob) {
+    EnvMap m;
+    m.w = (int)l.f[0], m.h = (int)l.f[1], m.probe = l.f[2] != 0;
+    m.texels = reinterpret_cast<const float*>(blob + (size_t)l.f[3]);
+    m.tables = reinterpret_cast<const double*>(blob + (size_t)l.f[4]);
+    return m;
+}
+RT_DEV Real dist1d_sample(const double* d, int n, Real u, Real& pdf_out, int& offset) { /* :30-45 */
+    const double *func = d, *cdf = d + n;
+    const Real func_int = d[2 * n + 1];
+    int lo = 0, hi = n + 1; /* std::lower_bound over cdf[0 .. n] */
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (cdf[mid] < u)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    offset = lo - 1 > 0 ? lo - 1 : 0;
+    offset = offset < n - 1 ? offset : n - 1;
+    Real du = u - cdf[offset];
+    const Real span = cdf[offset + 1] - cdf[offset];
+    if (span > 0) du /= span;
+    pdf_out = (func_int > 0) ? func[offset] / func_int : 0;
+    return (offset + du) / n;
+}
+RT_DEV Real dist1d_pdf(const double* d, int n, int index) { /* :47-49 */
+    const Real func_int = d[2 * n + 1];
+    return (func_int > 0) ? d[index] / (func_int * n) : 0;
+}
+RT_DEV V3 env_pixel(const EnvMap& m, int i, int j) { /* :276-289 */
+    if (i < 0) i += m.w;
+    if (i >= m.w) i -= m.w;
+    if (j < 0) j = 0;
+    if (j >= m.h) j = m.h - 1;
+    const float* t = m.texels + 3 * ((size_t)j * m.w + i);
+    return mk(t[0], t[1], t[2]);
+}
+/* direction -> map coordinates (:233-250, :299-315); returns theta of the polar axis of the mapping */
+RT_DEV Real env_uv(const EnvMap& m, V3 unit_dir, Real& u, Real& v) {
+    if (m.probe) {
+        const Real d = __builtin_sqrt(unit_dir.x * unit_dir.x + unit_dir.y * unit_dir.y);
+        const Real theta = acos(unit_dir.z);
+        const Real r_coord = (d > 0) ? (1.0 / RT_PI) * theta / d : 0.0;
+        u = (unit_dir.x * r_coord + 1.0) * 0.5;
+        v = (unit_dir.y * r_coord + 1.0) * 0.5;
+        v = 1.0 - v;
+        return theta;
+    }
+    const Real theta = acos(unit_dir.y);
+    const Real phi = atan2(-unit_dir.z, unit_dir.x) + RT_PI;
+    u = phi / (2 * RT_PI);
+    v = theta / RT_PI;
+    return theta;
+}
+RT_DEV V3 env_Le(const EnvMap& m, V3 direction) { /* :226-274 */
+    Real u, v;
+    env_uv(m, unit(direction), u, v);
+    const Real u_img = u * m.w - 0.5;
+    const Real v_img = v * m.h - 0.5;
+    const int i0 = (int)floor(u_img);
+    const int j0 = (int)floor(v_img);
+    const Real du = u_img - i0;
+    const Real dv = v_img - j0;
+    const V3 c00 = env_pixel(m, i0, j0), c10 = env_pixel(m, i0 + 1, j0);
+    const V3 c01 = env_pixel(m, i0, j0 + 1), c11 = env_pixel(m, i0 + 1, j0 + 1);
+    const V3 c0 = add(scl(1 - du, c00), scl(du, c10));
+    const V3 c1 = add(scl(1 - du, c01), scl(du, c11));
+    return add(scl(1 - dv, c0), scl(dv, c1));
+}
+RT_DEV LightSample env_sample(const EnvMap& m, Real ux, Real uy) { /* :182-224 */
     LightSample s;
-    const int type = l.type;
+    s.dist = RT_INF;
+    s.is_delta = false;
+    s.wi = mk(0, 0, 0);
+    s.Li = mk(0, 0, 0);
+    s.pdf = 0;
+    Real pdfs[2];
+    int v_idx, u_idx, n;
+    const double* marg = m.dist(m.h, n);
+    const Real v = dist1d_sample(marg, n, uy, pdfs[1], v_idx);
+    const double* cond = m.dist(v_idx, n);
+    const Real u = dist1d_sample(cond, n, ux, pdfs[0], u_idx);
+    const Real map_pdf = pdfs[0] * pdfs[1];
+    if (map_pdf == 0) return s;
+    Real phi, theta;
+    if (m.probe) {
+        const Real uc = u * 2.0 - 1.0;
+        const Real vc = (1.0 - v) * 2.0 - 1.0;
+        const Real r = __builtin_sqrt(uc * uc + vc * vc);
+        if (r > 1.0) return s;
+        theta = RT_PI * r;
+        phi = atan2(vc, uc);
+        const Real sin_theta = sin(theta);
+        s.wi = mk(sin_theta * cos(phi), sin_theta * sin(phi), cos(theta));
+    } else {
+        phi = u * 2 * RT_PI - RT_PI;
+        theta = v * RT_PI;
+        const Real sin_theta = sin(theta);
+        const Real cos_theta = cos(theta);
+        s.wi = mk(sin_theta * cos(phi), cos_theta, -sin_theta * sin(phi));
+    }
+    const Real sin_theta = sin(theta);
+    if (sin_theta < 1e-6) return s;
+    s.pdf = map_pdf * m.w * m.h / (2.0 * RT_PI * RT_PI * sin_theta);
+    s.Li = env_Le(m, s.wi);
+    return s;
+}
+RT_DEV Real env_pdf(const EnvMap& m, V3 direction) { /* :291-331 */
+    Real u, v;
+    const Real theta = env_uv(m, unit(direction), u, v);
+    const Real sin_theta = sin(theta);
+    if (sin_theta < 1e-6) return 0;
+    const int u_idx = (int)clampd((int)(u * m.w), 0, m.w - 1);
+    const int v_idx = (int)clampd((int)(v * m.h), 0, m.h - 1);
+    int n;
+    const double* cond = m.dist(v_idx, n);
+    const Real pu = dist1d_pdf(cond, n, u_idx);
+    const double* marg = m.dist(m.h, n);
+    const Real map_pdf = pu * dist1d_pdf(marg, n, v_idx);
+    return map_pdf * m.w * m.h / (2.0 * RT_PI * RT_PI * sin_theta);
+}
+
+/* MS == RT_MS_LEAN kernels serve scenes lit by QuadLights only (rtr_upload_scene decides) */
+template <int MS = RT_MS_FULL>
+RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy, uint32_t& rng, const uint8_t* blob) {
+    LightSample s;
+    const int type = MS == RT_MS_LEAN ? (int)RTR_LIGHT_QUAD : l.type;
+    if (type == RTR_LIGHT_ENV_MAP) return env_sample(env_map(l, blob), ux, uy);
     if (type == RTR_LIGHT_ENV_UNIFORM) { /* lighting/environmental_light.h:182-192 (no map loaded) */
         s.dist = RT_INF;
         s.is_delta = false;
@@ -1271,9 +1409,13 @@ RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy, uint
     s.pdf = dist_sq / (l.f[15] * cos_theta);
     return s;
 }
-RT_DEV Real light_pdf(const rtr_light& l, V3 origin, V3 direction) {
-    if (l.type == RTR_LIGHT_ENV_UNIFORM) return 1.0 / (4.0 * RT_PI); /* environmental_light.h:293-294 */
-    if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf (light.h:26-28): delta lights */
+template <int MS = RT_MS_FULL>
+RT_DEV Real light_pdf(const rtr_light& l, V3 origin, V3 direction, const uint8_t* blob) {
+    if (MS != RT_MS_LEAN) {
+        if (l.type == RTR_LIGHT_ENV_UNIFORM) return 1.0 / (4.0 * RT_PI); /* environmental_light.h:293-294 */
+        if (l.type == RTR_LIGHT_ENV_MAP) return env_pdf(env_map(l, blob), direction);
+        if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf (light.h:26-28): delta lights */
+    }
     V3 Q = ld3(l.f), U = ld3(l.f + 3), Vv = ld3(l.f + 6), normal = ld3(l.f + 12);
     Real denom = dot(direction, normal);
     if (denom >= -1e-6) return 0;
@@ -1314,12 +1456,13 @@ RT_DEV Real power_heuristic(Real pdf_a, Real pdf_b) { /* :165-170 */
     Real denom = a2 + b2;
     return denom > 0 ? a2 / denom : 0.0;
 }
+template <int MS = RT_MS_FULL>
 RT_DEV Real compute_light_pdf(const DScene& sc, V3 o, V3 d) { /* :173-188 */
     Real total_pdf = 0.0;
     Real light_select_pdf = 1.0 / sc.n_lights;
     for (int k = 0; k < sc.n_lights; ++k) {
         const rtr_light l = ld_const(sc.lights, k); /* wave-uniform index: scalar loads */
-        total_pdf += light_pdf(l, o, d) * light_select_pdf;
+        total_pdf += light_pdf<MS>(l, o, d, sc.image_bytes) * light_select_pdf;
     }
     return total_pdf;
 }
@@ -1328,23 +1471,26 @@ RT_DEV Real compute_light_pdf(const DScene& sc, V3 o, V3 d) { /* :173-188 */
  * mis_path_integrator.h:37-67, direct_light_integrator.h:41-54; the other integrators only know
  * the background colour.  The only infinite light flattened is the map-less EnvironmentLight,
  * whose Le is (1,1,1) (environmental_light.h:226-229). */
-template <int INTEG>
+template <int INTEG, int MS = RT_MS_FULL>
 RT_DEV V3 miss_radiance(const DScene& sc, V3 thr, V3 ro, V3 rd, int depth, bool specular_bounce, Real prev_bsdf_pdf) {
-    if (INTEG == RTR_INTEGRATOR_MIS || INTEG == RTR_INTEGRATOR_NEE) {
+    if (MS != RT_MS_LEAN && (INTEG == RTR_INTEGRATOR_MIS || INTEG == RTR_INTEGRATOR_NEE)) {
         V3 env = mk(0, 0, 0);
         bool found = false;
-        for (int k = 0; k < sc.n_lights; ++k)
-            if (sc.lights[k].type == RTR_LIGHT_ENV_UNIFORM) {
-                if (INTEG == RTR_INTEGRATOR_NEE)
-                    env = add(env, mul(thr, mk(1, 1, 1))); /* L += throughput * Le, light by light */
-                else
-                    env = add(env, mk(1, 1, 1));
-                found = true;
-            }
+        for (int k = 0; k < sc.n_lights; ++k) {
+            const int type = sc.lights[k].type;
+            if (type != RTR_LIGHT_ENV_UNIFORM && type != RTR_LIGHT_ENV_MAP) continue;
+            V3 le = mk(1, 1, 1); /* environmental_light.h:226-229 */
+            if (type == RTR_LIGHT_ENV_MAP) le = env_Le(env_map(sc.lights[k], sc.image_bytes), rd);
+            if (INTEG == RTR_INTEGRATOR_NEE)
+                env = add(env, mul(thr, le)); /* L += throughput * Le, light by light */
+            else
+                env = add(env, le);
+            found = true;
+        }
         if (found) {
             if (INTEG == RTR_INTEGRATOR_NEE) return env;
             if (depth == 0 || specular_bounce) return mul(thr, env);
-            const Real mis_weight = power_heuristic(prev_bsdf_pdf, compute_light_pdf(sc, ro, rd));
+            const Real mis_weight = power_heuristic(prev_bsdf_pdf, compute_light_pdf<MS>(sc, ro, rd));
             return scl(mis_weight, mul(thr, env));
         }
     }
@@ -1412,7 +1558,7 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
             if (ps.depth == 0 || ps.specular_bounce) {
                 L_emit = mul(ps.thr, emitted);
             } else if (have_lights) {
-                Real mis_weight = power_heuristic(ps.prev_bsdf_pdf, compute_light_pdf(sc, ps.ro, ps.rd));
+                Real mis_weight = power_heuristic(ps.prev_bsdf_pdf, compute_light_pdf<MS>(sc, ps.ro, ps.rd));
                 L_emit = scl(mis_weight, mul(ps.thr, emitted));
             } else {
                 L_emit = mul(ps.thr, emitted);
@@ -1429,9 +1575,9 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
         LightSample ls;
         if (sc.n_lights == 1) { /* the usual case: the record comes in through scalar loads, not 34 VGPRs */
             const rtr_light l0 = ld_const(sc.lights, 0);
-            ls = light_sample(l0, rec.p, ux, uy, rng);
+            ls = light_sample<MS>(l0, rec.p, ux, uy, rng, sc.image_bytes);
         } else {
-            ls = light_sample(sc.lights[light_idx], rec.p, ux, uy, rng);
+            ls = light_sample<MS>(sc.lights[light_idx], rec.p, ux, uy, rng, sc.image_bytes);
         }
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
             V3 f = mat_eval<MS>(sc, rec, wo, ls.wi);

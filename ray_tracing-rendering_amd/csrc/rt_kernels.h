@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                 const bool hit_any = cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st);
                 RTR_CLK(clk_closest);
                 if (!hit_any) {
-                    pk.set3(PK_L, add(pk.get3(PK_L), miss_radiance<INTEG>(sc, pk.get3(PK_THR), ps.ro, ps.rd, ps.depth,
+                    pk.set3(PK_L, add(pk.get3(PK_L), miss_radiance<INTEG, MS>(sc, pk.get3(PK_THR), ps.ro, ps.rd, ps.depth,
                                                                           ps.specular_bounce, pk.get(PK_PDF))));
                     ended = true;
                 } else {
@@ -338,11 +338,11 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_lights(const DScene sc, rtr_
     rtr_light_record r = recs[k];
     const rtr_light& l = sc.lights[r.light];
     uint32_t rng = 0x2545F491u; /* the uniform environment light draws its direction itself */
-    LightSample s = light_sample(l, ld3(r.p), r.u[0], r.u[1], rng);
+    LightSample s = light_sample(l, ld3(r.p), r.u[0], r.u[1], rng, sc.image_bytes);
     r.Li[0] = s.Li.x, r.Li[1] = s.Li.y, r.Li[2] = s.Li.z;
     r.wi[0] = s.wi.x, r.wi[1] = s.wi.y, r.wi[2] = s.wi.z;
     r.pdf = s.pdf, r.dist = s.dist, r.is_delta = s.is_delta, r.pad2 = 0;
-    r.pdf_dir = light_pdf(l, ld3(r.p), ld3(r.dir));
+    r.pdf_dir = light_pdf(l, ld3(r.p), ld3(r.dir), sc.image_bytes);
     recs[k] = r;
 }
 

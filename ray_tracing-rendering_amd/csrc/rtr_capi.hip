@@ -41,7 +41,7 @@ struct rtr_context {
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool force_exact = false;
-    bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures */
+    bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
     int n_material_types = 0;
     /* per-render workspace */
     DevBuf b_tiles, b_partial, b_stats, b_cancel, b_test;
@@ -240,9 +240,21 @@ struct Validator {
             (s->n_textures && !s->textures) || (s->n_perlin && !s->perlin) || (s->n_images && !s->images) ||
             (s->n_image_bytes && !s->image_bytes) || (s->n_lights && !s->lights))
             return (bad(RTR_ERR_INVALID, "null array with non-zero count"), code);
-        for (int k = 0; k < s->n_lights; ++k)
-            if (s->lights[k].type < 0 || s->lights[k].type >= RTR_LIGHT_TYPE_COUNT)
-                return (bad(RTR_ERR_UNSUPPORTED, "unknown light type (QuadLight, PointLight, SpotLight, DirectionalLight are on the device)"), code);
+        for (int k = 0; k < s->n_lights; ++k) {
+            const rtr_light& l = s->lights[k];
+            if (l.type < 0 || l.type >= RTR_LIGHT_TYPE_COUNT)
+                return (bad(RTR_ERR_UNSUPPORTED, "unknown light type (QuadLight, PointLight, SpotLight, DirectionalLight, EnvironmentLight are on the device)"), code);
+            if (l.type == RTR_LIGHT_ENV_MAP) { /* texels and sampling tables live in image_bytes */
+                const double w = l.f[0], h = l.f[1], to = l.f[3], tb = l.f[4];
+                if (!(w >= 1 && h >= 1 && w <= 65536 && h <= 65536) || w != (double)(int)w || h != (double)(int)h)
+                    return (bad(RTR_ERR_INVALID, "environment map size out of range"), code);
+                const double nb = (double)s->n_image_bytes;
+                const double texel_bytes = w * h * 3 * 4, table_bytes = (h * (2 * w + 2) + (2 * h + 2)) * 8;
+                if (!(to >= 0 && tb >= 0) || to != (double)(uint64_t)to || tb != (double)(uint64_t)tb ||
+                    (uint64_t)to % 4 || (uint64_t)tb % 8 || to + texel_bytes > nb || tb + table_bytes > nb)
+                    return (bad(RTR_ERR_INVALID, "environment map texels / tables out of range or misaligned"), code);
+            }
+        }
         state.assign(s->n_nodes, 0);
         need.assign(s->n_nodes, 0);
         depth.assign(s->n_nodes, 0);
@@ -570,6 +582,8 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     unsigned type_mask = 0;
     for (int k = 0; k < s->n_materials; ++k) type_mask |= 1u << s->materials[k].type;
     c->n_material_types = __builtin_popcount(type_mask);
+    for (int k = 0; k < s->n_lights; ++k)
+        if (s->lights[k].type != RTR_LIGHT_QUAD) c->lean_materials = false; /* the lean kernels know QuadLights only */
     for (int k = 0; k < s->n_materials; ++k) {
         const rtr_material& m = s->materials[k];
         if (m.type != RTR_MAT_LAMBERTIAN && m.type != RTR_MAT_DIFFUSE_LIGHT) c->lean_materials = false;

@@ -323,18 +323,27 @@ def test_next_integrators(ctx, sid, integ, img_name):
     assert e.value.code == A.RTR_ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("sid", [15, 17, 18, 19])
-def test_delta_lights(ctx, sid):
-    """PointLight (scene 15), DirectionalLight (17), SpotLight (18): light records,
-    per-sample records and images vs the reference, both pipelines."""
+@pytest.mark.parametrize("sid", [15, 17, 18, 19, 24, 26])
+def test_delta_and_environment_lights(ctx, sid):
+    """PointLight (scene 15), DirectionalLight (17), SpotLight (18), EnvironmentLight
+    without a map (19), with an equirectangular HDR map (24) and with an angular-probe map (26):
+    light records, per-sample records and images vs the reference, both pipelines."""
     sc = _upload(ctx, sid)
     gold = G.records("lights_scene%02d.bin" % sid, A.LIGHTREC_DTYPE)
     out = ctx.test_records("lights", gold)
-    for f in ("Li", "wi", "pdf", "dist", "pdf_dir"):
-        assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
+    if sid in (24, 26):  # sin / cos / acos / atan2 come from OCML here, glibc there
+        assert np.array_equal(out["pdf"] == 0, gold["pdf"] == 0)
+        for f in ("Li", "pdf", "pdf_dir"):  # an ulp in (u,v) can select the neighbouring texel: rare
+            same_nan = np.isnan(out[f]) & np.isnan(gold[f])  # pdf() of the zero direction of a failed sample
+            assert (_close(out[f], gold[f], 1e-9) | same_nan).mean() >= 0.99, f
+        assert np.abs(out["wi"] - gold["wi"]).max() <= 1e-12
+        assert np.all(np.isinf(out["dist"]))
+    else:
+        for f in ("Li", "wi", "pdf", "dist", "pdf_dir"):
+            assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
     assert np.array_equal(out["is_delta"], gold["is_delta"])
     cases = [(4, "img_scene%02d_i4_64_spp16.f64" % sid)] + \
-            ([(3, "img_scene%02d_i3_64_spp16.f64" % sid)] if sid in (18, 19) else [])  # 19: uniform EnvironmentLight
+            ([(3, "img_scene%02d_i3_64_spp16.f64" % sid)] if sid in (18, 19, 24, 26) else [])  # 19: uniform EnvironmentLight
     for integ, img_name in cases:
         name = "li_scene%02d_i%d.bin" % (sid, integ)
         info = G.MANIFEST["files"][name]

@@ -84,7 +84,7 @@ def test_material_vectors(sid):
     assert set(np.unique(types)) >= ({A.MAT_LAMBERTIAN, A.MAT_DIELECTRIC, A.MAT_DIFFUSE_LIGHT})
 
 
-@pytest.mark.parametrize("sid", [21, 23, 15, 17, 18, 19])
+@pytest.mark.parametrize("sid", [21, 23, 15, 17, 18, 19, 24, 26])
 def test_light_vectors(sid):
     """QuadLight / PointLight / DirectionalLight / SpotLight sample() and pdf() (lighting/*.h)."""
     sc = G.scene(sid)
@@ -97,12 +97,19 @@ def test_light_vectors(sid):
         assert (gold["pdf"] > 0).any() and (gold["pdf"] == 0).any()
     elif sid == 19:  # map-less EnvironmentLight: uniform sphere
         assert not gold["is_delta"].any() and np.all(gold["pdf"] == 1.0 / (4.0 * np.pi)) and np.all(np.isinf(gold["dist"]))
+    elif sid in (24, 26):  # EnvironmentLight with a (synthetic) HDR map: 24 equirectangular, 26 angular probe
+        assert sc.lights["type"][0] == A.LIGHT_ENV_MAP and sc.lights["f"][0][2] == (1.0 if sid == 26 else 0.0)
+        assert not gold["is_delta"].any() and np.all(np.isinf(gold["dist"]))
+        assert (gold["pdf"] > 0).mean() > 0.5 and len(np.unique(gold["pdf"])) > 20  # importance sampled, not uniform
+        if sid == 26:
+            assert (gold["pdf"] == 0).any()  # texels outside the probe's disc
     else:
         assert gold["is_delta"].all() and (gold["pdf_dir"] == 0).all()
 
 
 LI_CASES = [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4), (7, 0), (23, 2), (21, 3), (23, 3),
-            (15, 4), (17, 4), (18, 4), (18, 3), (4, 1), (19, 4), (19, 3), (1, 1), (8, 1)]
+            (15, 4), (17, 4), (18, 4), (18, 3), (4, 1), (19, 4), (19, 3), (1, 1), (8, 1),
+            (24, 4), (24, 3), (26, 4), (26, 3)]
 
 
 @pytest.mark.parametrize("sid,integ", LI_CASES)
@@ -116,7 +123,7 @@ def test_li_records(sid, integ):
                       seed=info["seed"])
     out = G.oracle_records(sc, "rto_li", gold, params=p)
     assert np.array_equal(out["rng_exit"], gold["rng_exit"])
-    if sid in (17, 19):
+    if sid in (17, 19, 24, 26):
         # a directional light (and the environment light: dist = inf)'s shadow ray has t_max = inf - 0.001 = inf, which the harness's
         # counting wrapper (finite t_max = shadow ray) files under "closest": compare the total
         assert np.array_equal(out["n_closest"] + out["n_shadow"], gold["n_closest"] + gold["n_shadow"])
@@ -133,7 +140,8 @@ IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_
              "img_scene21_i3_64_spp16.f64", "img_scene23_i3_64_spp16.f64", "img_scene15_i4_64_spp16.f64",
              "img_scene17_i4_64_spp16.f64", "img_scene18_i4_64_spp16.f64", "img_scene18_i3_64_spp16.f64",
              "img_scene04_i1_64_spp16.f64", "img_scene19_i4_64_spp16.f64", "img_scene19_i3_64_spp16.f64", "img_scene01_i1_64_spp16.f64",
-             "img_scene08_i1_64_spp16.f64"]
+             "img_scene08_i1_64_spp16.f64", "img_scene24_i4_64_spp16.f64", "img_scene24_i3_64_spp16.f64",
+             "img_scene26_i4_64_spp16.f64", "img_scene26_i3_64_spp16.f64"]
 
 
 @pytest.mark.parametrize("name", IMG_CASES)
@@ -144,7 +152,7 @@ def test_images(name):
     p = A.make_params(info["width"], info["height"], info["spp"], integrator=info["integrator"], seed=info["seed"])
     out, stats = G.oracle_render(sc, p, threads=4)
     assert stats["samples"] == info["width"] * info["height"] * info["spp"]
-    if info["scene"] in (17, 19):  # see test_li_records
+    if info["scene"] in (17, 19, 24, 26):  # see test_li_records
         assert stats["closest_segments"] + stats["shadow_segments"] == \
             info["info"]["closest_segments"] + info["info"]["shadow_segments"]
     else:
