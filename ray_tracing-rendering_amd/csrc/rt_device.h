@@ -942,6 +942,8 @@ __device__ inline V3 tex_value_slow(const DScene& sc, int ix, Real u, Real v, V3
  * Cook-Torrance / pow() / perlin out of their register budget.  RT_MS_FULL handles everything. */
 #define RT_MS_LEAN 0
 #define RT_MS_FULL 1
+#define RT_MS_QUADLIT 2 /* every material, but only QuadLights: keeps the delta / environment light code
+                           (binary searches, sin / cos / acos / atan2) out of e.g. scene 23's kernel */
 
 template <int MS = RT_MS_FULL>
 RT_DEV V3 tex_value(const DScene& sc, int ix, Real u, Real v, V3 p) {
@@ -1356,11 +1358,11 @@ RT_DEV Real env_pdf(const EnvMap& m, V3 direction) { /* :291-331 */
     return map_pdf * m.w * m.h / (2.0 * RT_PI * RT_PI * sin_theta);
 }
 
-/* MS == RT_MS_LEAN kernels serve scenes lit by QuadLights only (rtr_upload_scene decides) */
+/* only MS == RT_MS_FULL kernels know lights other than QuadLights (rtr_upload_scene decides) */
 template <int MS = RT_MS_FULL>
 RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy, uint32_t& rng, const uint8_t* blob) {
     LightSample s;
-    const int type = MS == RT_MS_LEAN ? (int)RTR_LIGHT_QUAD : l.type;
+    const int type = MS != RT_MS_FULL ? (int)RTR_LIGHT_QUAD : l.type;
     if (type == RTR_LIGHT_ENV_MAP) return env_sample(env_map(l, blob), ux, uy);
     if (type == RTR_LIGHT_ENV_UNIFORM) { /* lighting/environmental_light.h:182-192 (no map loaded) */
         s.dist = RT_INF;
@@ -1411,7 +1413,7 @@ RT_DEV LightSample light_sample(const rtr_light& l, V3 p, Real ux, Real uy, uint
 }
 template <int MS = RT_MS_FULL>
 RT_DEV Real light_pdf(const rtr_light& l, V3 origin, V3 direction, const uint8_t* blob) {
-    if (MS != RT_MS_LEAN) {
+    if (MS == RT_MS_FULL) {
         if (l.type == RTR_LIGHT_ENV_UNIFORM) return 1.0 / (4.0 * RT_PI); /* environmental_light.h:293-294 */
         if (l.type == RTR_LIGHT_ENV_MAP) return env_pdf(env_map(l, blob), direction);
         if (l.type != RTR_LIGHT_QUAD) return 0.0; /* Light::pdf (light.h:26-28): delta lights */
@@ -1473,7 +1475,7 @@ RT_DEV Real compute_light_pdf(const DScene& sc, V3 o, V3 d) { /* :173-188 */
  * whose Le is (1,1,1) (environmental_light.h:226-229). */
 template <int INTEG, int MS = RT_MS_FULL>
 RT_DEV V3 miss_radiance(const DScene& sc, V3 thr, V3 ro, V3 rd, int depth, bool specular_bounce, Real prev_bsdf_pdf) {
-    if (MS != RT_MS_LEAN && (INTEG == RTR_INTEGRATOR_MIS || INTEG == RTR_INTEGRATOR_NEE)) {
+    if (MS == RT_MS_FULL && (INTEG == RTR_INTEGRATOR_MIS || INTEG == RTR_INTEGRATOR_NEE)) {
         V3 env = mk(0, 0, 0);
         bool found = false;
         for (int k = 0; k < sc.n_lights; ++k) {

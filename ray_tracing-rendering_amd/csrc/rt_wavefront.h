@@ -441,6 +441,7 @@ inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
 /* Runs the whole render on `stream` and returns when it has finished (the iteration loop is
  * driven from the host, which polls the live-slot counter every `check` iterations). */
 inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool has_lights, const bool lean,
+                            const bool quadlit,
                             const bool sort, const int trav, const size_t lds, const RenderK& Pin, int integrator,
                             double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<int>* cancel,
                             int* launches, std::string& err) {
@@ -507,6 +508,8 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
             } else if (!media) {
                 if (lean)
                     WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_LEAN);
+                else if (quadlit)
+                    WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_QUADLIT);
                 else
                     WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_FULL);
                 if (has_lights) {
@@ -516,7 +519,10 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
                         WF_CONNECT(RT_TRAV_EXACT);
                 }
             } else {
-                WF_SHADE(RTR_INTEGRATOR_MIS, 1, RT_MS_FULL);
+                if (quadlit)
+                    WF_SHADE(RTR_INTEGRATOR_MIS, 1, RT_MS_QUADLIT);
+                else
+                    WF_SHADE(RTR_INTEGRATOR_MIS, 1, RT_MS_FULL);
                 if (has_lights) {
                     if (trav == RT_TRAV_PROGRAM)
                         WF_CONNECT(RT_TRAV_PROGRAM);

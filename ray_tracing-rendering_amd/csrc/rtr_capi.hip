@@ -42,6 +42,7 @@ struct rtr_context {
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool force_exact = false;
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
+    bool quad_lights_only = false;
     int n_material_types = 0;
     /* per-render workspace */
     DevBuf b_tiles, b_partial, b_stats, b_cancel, b_test;
@@ -338,21 +339,28 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
     const DScene* dsc = static_cast<const DScene*>(c->b_dscene.p);
     const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
     const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
+    const bool quadlit = c->quad_lights_only;
 #define RTR_LAUNCH(I, T, M)                                                                        \
     do {                                                                                           \
         int rc_ = set_lds(c, k_mega<I, T, M>, lds);                                                \
         if (rc_) return rc_;                                                                       \
         hipLaunchKernelGGL((k_mega<I, T, M>), grid, block, lds, c->stream, dsc, P, stack_words);   \
     } while (0)
-#define RTR_LAUNCH_T(I)                                                     \
+/* FULLQ = the variant for "every material, QuadLights only" (the RR integrator has no light code) */
+#define RTR_LAUNCH_T(I, FULLQ)                                              \
     do {                                                                    \
         if (trav == RT_TRAV_FAST) {                                         \
             if (lean)                                                       \
                 RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_LEAN);                    \
+            else if (quadlit)                                               \
+                RTR_LAUNCH(I, RT_TRAV_FAST, FULLQ);                         \
             else                                                            \
                 RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);                    \
         } else if (trav == RT_TRAV_PROGRAM) {                               \
-            RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);                     \
+            if (quadlit)                                                    \
+                RTR_LAUNCH(I, RT_TRAV_PROGRAM, FULLQ);                      \
+            else                                                            \
+                RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);                 \
         } else if (trav == RT_TRAV_MEDIA) {                                 \
             RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);                       \
         } else {                                                            \
@@ -374,8 +382,8 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
             RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);      \
     } while (0)
     switch (integrator) {
-    case RTR_INTEGRATOR_MIS: RTR_LAUNCH_T(RTR_INTEGRATOR_MIS); break;
-    case RTR_INTEGRATOR_RR: RTR_LAUNCH_T(RTR_INTEGRATOR_RR); break;
+    case RTR_INTEGRATOR_MIS: RTR_LAUNCH_T(RTR_INTEGRATOR_MIS, RT_MS_QUADLIT); break;
+    case RTR_INTEGRATOR_RR: RTR_LAUNCH_T(RTR_INTEGRATOR_RR, RT_MS_FULL); break;
     case RTR_INTEGRATOR_PATH: RTR_LAUNCH_N1(RTR_INTEGRATOR_PATH); break;
     case RTR_INTEGRATOR_PBR: RTR_LAUNCH_N1(RTR_INTEGRATOR_PBR); break;
     default: RTR_LAUNCH_N1(RTR_INTEGRATOR_NEE); break;
@@ -582,8 +590,10 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     unsigned type_mask = 0;
     for (int k = 0; k < s->n_materials; ++k) type_mask |= 1u << s->materials[k].type;
     c->n_material_types = __builtin_popcount(type_mask);
+    c->quad_lights_only = true;
     for (int k = 0; k < s->n_lights; ++k)
-        if (s->lights[k].type != RTR_LIGHT_QUAD) c->lean_materials = false; /* the lean kernels know QuadLights only */
+        if (s->lights[k].type != RTR_LIGHT_QUAD) c->quad_lights_only = false;
+    if (!c->quad_lights_only) c->lean_materials = false; /* the lean kernels know QuadLights only */
     for (int k = 0; k < s->n_materials; ++k) {
         const rtr_material& m = s->materials[k];
         if (m.type != RTR_MAT_LAMBERTIAN && m.type != RTR_MAT_DIFFUSE_LIGHT) c->lean_materials = false;
@@ -645,7 +655,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
         const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
-        rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean,
+        rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean, c->quad_lights_only,
                               !lean && c->n_material_types > 1, trav, stack_bytes(c, trav), P, p->integrator, d_rgb,
                               row_stride, c->stream, &c->cancel_requested, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
