@@ -23,6 +23,22 @@ HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 SCENE_SEED = 12345  # xorshift state before select_scene(): BVH axes, perlin tables, random geometry
 
 
+def write_hdr(path, w, h, sun):
+    px = bytearray()
+    for j in range(h):
+        for i in range(w):
+            e = 128 + (i + 2 * j) % 3
+            if (i, j) in sun:
+                e = 135
+            px += bytes((40 + (i * 7 + j * 3) % 200, 30 + (i * 5 + j * 11) % 200, 20 + (i * 3 + j * 13) % 220, e))
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(px))
+
+
+HDR_ASSETS = {24: ("brown_photostudio_02_4k.hdr", 32, 16, {(20, 4), (21, 4), (20, 5)}),
+              26: ("rnl_probe.hdr", 16, 16, {(11, 5), (4, 9)})}
+
+
 def run(*args, cwd=None):
     cmd = [HARNESS] + [str(a) for a in args]
     out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=cwd).stdout.decode()
@@ -131,20 +147,9 @@ def main():
     # so two small synthetic Radiance RGBE pictures (flat scanlines, which stb_image's stbi_loadf
     # accepts) are written under the names scenes 24 / 26 ask for: a 32x16 equirectangular map with
     # a bright "sun" and a 16x16 square map, which the reference treats as an angular light probe.
-    def write_hdr(path, w, h, sun):
-        px = bytearray()
-        for j in range(h):
-            for i in range(w):
-                e = 128 + (i + 2 * j) % 3
-                if (i, j) in sun:
-                    e = 135
-                px += bytes((40 + (i * 7 + j * 3) % 200, 30 + (i * 5 + j * 11) % 200, 20 + (i * 3 + j * 13) % 220, e))
-        with open(path, "wb") as f:
-            f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(px))
-
     with tempfile.TemporaryDirectory() as td:
-        write_hdr(os.path.join(td, "brown_photostudio_02_4k.hdr"), 32, 16, {(20, 4), (21, 4), (20, 5)})
-        write_hdr(os.path.join(td, "rnl_probe.hdr"), 16, 16, {(11, 5), (4, 9)})
+        for fname, w, h, sun in HDR_ASSETS.values():
+            write_hdr(os.path.join(td, fname), w, h, sun)
         for sid, what in ((24, "synthetic 32x16 RGBE as brown_photostudio_02_4k.hdr (equirectangular)"),
                           (26, "synthetic 16x16 RGBE as rnl_probe.hdr (angular probe)")):
             name = "scene%02d.rtrs" % sid

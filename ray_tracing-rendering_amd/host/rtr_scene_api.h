@@ -605,6 +605,11 @@ class Light {
         why = "this Light subclass has no device implementation";
         return false;
     }
+    /* lights with bulk data (environment maps) append it to the scene's byte blob */
+    virtual bool rtr_flatten(rtr_light& out, std::vector<uint8_t>& blob, std::string& why) const {
+        (void)blob;
+        return rtr_flatten(out, why);
+    }
 };
 
 class QuadLight : public Light { /* lighting/quad_light.h:9-17 */
@@ -677,13 +682,23 @@ class DirectionalLight : public Light {
     vec3 direction;
     color L;
 };
-/* EnvironmentLight (lighting/environmental_light.h:120-374).  No HDR decoder ships with this layer
- * and none of the reference's maps exist, so the map is always "missing", which is the
- * reference's own behaviour in this checkout: a uniform white sky (:126-131,187-192,226-229,293-294). */
+/* EnvironmentLight (lighting/environmental_light.h:120-374).  The map is read by this layer's own
+ * Radiance RGBE reader (flat and run-length scanlines; texel = mantissa * 2^(e-136) in float, the
+ * conversion stbi_loadf applies), the luminance * sin(theta) table and its Distribution2D are built
+ * like :147-179,:14-26,:64-80, and everything is handed to the device through the scene's byte blob
+ * (rtr_hip.h, RTR_LIGHT_ENV_MAP).  A file that cannot be read gives the reference's own fallback:
+ * a uniform white sky (:126-131,187-192,226-229,293-294). */
 class EnvironmentLight : public Light {
   public:
     EnvironmentLight(const char* map_filename) : filename(map_filename ? map_filename : "") {
-        std::cerr << "ERROR: Could not load HDR environment map: " << filename << std::endl;
+        if (!load_rgbe(filename.c_str())) {
+            std::cerr << "ERROR: Could not load HDR environment map: " << filename << std::endl;
+            width = height = 0;
+            hdr_data.clear();
+            return;
+        }
+        is_light_probe = width > 0 && height > 0 && width == height; /* :137-140 */
+        build_distribution();
     }
     bool is_infinite() const override { return true; }
     bool rtr_flatten(rtr_light& out, std::string&) const override {
@@ -691,7 +706,141 @@ class EnvironmentLight : public Light {
         out.type = RTR_LIGHT_ENV_UNIFORM;
         return true;
     }
+    bool rtr_flatten(rtr_light& out, std::vector<uint8_t>& blob, std::string& why) const override {
+        if (width == 0 || height == 0) return rtr_flatten(out, why);
+        out = rtr_light{};
+        out.type = RTR_LIGHT_ENV_MAP;
+        auto append = [&blob](const void* p, size_t n) {
+            const uint8_t* b = static_cast<const uint8_t*>(p);
+            blob.insert(blob.end(), b, b + n);
+        };
+        while (blob.size() % 8) blob.push_back(0);
+        out.f[0] = width, out.f[1] = height, out.f[2] = is_light_probe ? 1.0 : 0.0;
+        out.f[3] = (double)blob.size();
+        append(hdr_data.data(), hdr_data.size() * sizeof(float));
+        while (blob.size() % 8) blob.push_back(0);
+        out.f[4] = (double)blob.size();
+        append(tables.data(), tables.size() * sizeof(double));
+        return true;
+    }
     std::string filename;
+    std::vector<float> hdr_data;
+    std::vector<double> tables; /* per row {func[w], cdf[w+1], func_int}, then the marginal {func[h], cdf[h+1], func_int} */
+    int width = 0, height = 0;
+    bool is_light_probe = false;
+    double total_power = 0;
+
+  private:
+    /* Distribution1D::Distribution1D (:14-26), appended to `tables`; returns func_int */
+    double push_distribution(const std::vector<double>& func) {
+        const int n = (int)func.size();
+        std::vector<double> cdf(n + 1);
+        cdf[0] = 0;
+        for (int i = 1; i <= n; ++i) cdf[i] = cdf[i - 1] + func[i - 1];
+        const double func_int = cdf[n];
+        if (func_int > 0)
+            for (int i = 0; i <= n; ++i) cdf[i] /= func_int;
+        tables.insert(tables.end(), func.begin(), func.end());
+        tables.insert(tables.end(), cdf.begin(), cdf.end());
+        tables.push_back(func_int);
+        return func_int;
+    }
+    void build_distribution() { /* :147-179 */
+        std::vector<double> marginal_func(height);
+        total_power = 0;
+        for (int v = 0; v < height; ++v) {
+            const double sin_theta = sin(pi * (v + 0.5) / height);
+            std::vector<double> row(width);
+            for (int u = 0; u < width; ++u) {
+                const int pixel_idx = (v * width + u) * 3;
+                const double r = hdr_data[pixel_idx], g = hdr_data[pixel_idx + 1], b = hdr_data[pixel_idx + 2];
+                const double lum = 0.2126 * r + 0.7152 * g + 0.0722 * b;
+                row[u] = lum * sin_theta;
+            }
+            marginal_func[v] = push_distribution(row);
+        }
+        push_distribution(marginal_func);
+    }
+    static bool read_line(FILE* f, std::string& line) {
+        line.clear();
+        int ch;
+        while ((ch = std::fgetc(f)) != EOF && ch != '\n') line.push_back((char)ch);
+        return ch != EOF || !line.empty();
+    }
+    bool load_rgbe(const char* path) {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) return false;
+        bool ok = false;
+        do {
+            std::string line;
+            if (!read_line(f, line) || (line != "#?RADIANCE" && line != "#?RGBE")) break;
+            bool format_ok = false;
+            while (read_line(f, line) && !line.empty())
+                if (line == "FORMAT=32-bit_rle_rgbe") format_ok = true;
+            if (!format_ok || !read_line(f, line)) break;
+            int h = 0, w = 0;
+            if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0 || w > 65536 || h > 65536) break;
+            std::vector<unsigned char> rgbe((size_t)w * h * 4);
+            bool flat = w < 8 || w >= 32768;
+            size_t done_rows = 0;
+            if (!flat) {
+                std::vector<unsigned char> scan((size_t)w * 4);
+                for (int j = 0; j < h; ++j) {
+                    unsigned char hd[4];
+                    if (std::fread(hd, 1, 4, f) != 4) goto fail;
+                    if (hd[0] != 2 || hd[1] != 2 || (hd[2] & 0x80)) {
+                        if (j != 0) goto fail;
+                        /* not run-length encoded: these four bytes are the first texel of a flat file */
+                        std::memcpy(rgbe.data(), hd, 4);
+                        if (std::fread(rgbe.data() + 4, 1, rgbe.size() - 4, f) != rgbe.size() - 4) goto fail;
+                        done_rows = (size_t)h;
+                        break;
+                    }
+                    if (((hd[2] << 8) | hd[3]) != w) goto fail;
+                    for (int comp = 0; comp < 4; ++comp) {
+                        int i = 0;
+                        while (i < w) {
+                            int count = std::fgetc(f);
+                            if (count == EOF) goto fail;
+                            if (count > 128) {
+                                const int value = std::fgetc(f);
+                                count -= 128;
+                                if (value == EOF || count == 0 || count > w - i) goto fail;
+                                for (int z = 0; z < count; ++z) scan[(size_t)(i++) * 4 + comp] = (unsigned char)value;
+                            } else {
+                                if (count == 0 || count > w - i) goto fail;
+                                for (int z = 0; z < count; ++z) {
+                                    const int value = std::fgetc(f);
+                                    if (value == EOF) goto fail;
+                                    scan[(size_t)(i++) * 4 + comp] = (unsigned char)value;
+                                }
+                            }
+                        }
+                    }
+                    std::memcpy(rgbe.data() + (size_t)j * w * 4, scan.data(), scan.size());
+                    ++done_rows;
+                }
+            } else if (std::fread(rgbe.data(), 1, rgbe.size(), f) == rgbe.size()) {
+                done_rows = (size_t)h;
+            }
+            if (done_rows != (size_t)h) break;
+            hdr_data.resize((size_t)w * h * 3);
+            for (size_t k = 0; k < (size_t)w * h; ++k) {
+                const unsigned char* q = &rgbe[k * 4];
+                if (q[3] != 0) {
+                    const float f1 = (float)std::ldexp(1.0f, (int)q[3] - (128 + 8));
+                    hdr_data[k * 3] = q[0] * f1, hdr_data[k * 3 + 1] = q[1] * f1, hdr_data[k * 3 + 2] = q[2] * f1;
+                } else {
+                    hdr_data[k * 3] = hdr_data[k * 3 + 1] = hdr_data[k * 3 + 2] = 0;
+                }
+            }
+            width = w, height = h;
+            ok = true;
+        } while (false);
+    fail:
+        std::fclose(f);
+        return ok;
+    }
 };
 
 /* ---- renderer/camera.h:9-30 ------------------------------------------------------------------------------------------------ */
@@ -824,7 +973,7 @@ inline bool flatten(const hittable& world, const std::vector<shared_ptr<Light>>&
     for (const auto& l : lights) {
         rtr_light r{};
         std::string why;
-        if (!l->rtr_flatten(r, why)) f.fail(why);
+        if (!l->rtr_flatten(r, f.out.image_bytes, why)) f.fail(why);
         f.out.lights.push_back(r);
     }
     f.out.camera = cam.rtr_flatten();

@@ -61,6 +61,74 @@ def test_delta_light_scenes_drop_in(sid):
 
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_scenes is built only where the reference is")
+@pytest.mark.parametrize("sid", [24, 26])
+def test_environment_map_scenes_drop_in(sid):
+    """EnvironmentLight of the host layer (own RGBE reader, Distribution2D tables) on the synthetic
+    maps the goldens were made with: the flattened scene equals the one walked out of the
+    reference's objects (stb_image texels, its Distribution2D), byte for byte."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(G.ROOT, "oracle", "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fname, w, h, sun = gen.HDR_ASSETS[sid]
+    with tempfile.TemporaryDirectory() as td:
+        gen.write_hdr(os.path.join(td, fname), w, h, sun)
+        out = os.path.join(td, "s.rtrs")
+        r = subprocess.run([DROPIN, str(sid), "12345", out], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=td)
+        assert r.returncode == 0, r.stdout
+        assert open(out, "rb").read() == G.scene(sid).to_bytes()
+
+
+def _rle_scanline(row):
+    """Radiance adaptive run-length scanline: 2 2 hi lo, then each of the 4 components coded as runs
+    (count > 128: repeat) and literals (count <= 128)."""
+    w = len(row) // 4
+    out = bytearray((2, 2, w >> 8, w & 255))
+    for comp in range(4):
+        vals = row[comp::4]
+        i = 0
+        while i < w:
+            run = 1
+            while i + run < w and run < 127 and vals[i + run] == vals[i]:
+                run += 1
+            if run >= 3:
+                out += bytes((128 + run, vals[i]))
+                i += run
+            else:
+                lit = bytearray()
+                while i < w and len(lit) < 128:
+                    if i + 2 < w and vals[i] == vals[i + 1] == vals[i + 2]:
+                        break
+                    lit.append(vals[i])
+                    i += 1
+                out += bytes((len(lit),)) + bytes(lit)
+    return bytes(out)
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_scenes is built only where the reference is")
+def test_environment_map_run_length_scanlines():
+    """The same picture stored with run-length scanlines decodes to the same scene as the flat file."""
+    w, h = 32, 16
+    px = bytearray()
+    for j in range(h):
+        for i in range(w):
+            px += bytes((40 + (i // 5) * 9, 30 + (j * 11) % 200, 20 + (i * 3 + j * 13) % 220, 128 + (j % 3)))
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    outs = []
+    for body in (bytes(px), b"".join(_rle_scanline(px[j * w * 4:(j + 1) * w * 4]) for j in range(h))):
+        with tempfile.TemporaryDirectory() as td:
+            with open(os.path.join(td, "brown_photostudio_02_4k.hdr"), "wb") as f:
+                f.write(head + body)
+            out = os.path.join(td, "s.rtrs")
+            r = subprocess.run([DROPIN, "24", "12345", out], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=td)
+            assert r.returncode == 0, r.stdout
+            outs.append(open(out, "rb").read())
+    sc = rtr.Scene.from_bytes(outs[0])
+    assert sc.lights["type"][0] == G.A.LIGHT_ENV_MAP and (sc.lights["f"][0][0], sc.lights["f"][0][1]) == (w, h)
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_scenes is built only where the reference is")
 def test_every_reference_scene_flattens():
     """All scene ids of the reference's select_scene (scenes.cpp:1523-2096) build against the host
     layer and flatten to something the device accepts (environment maps are absent -> uniform sky)."""
