@@ -35,6 +35,32 @@ def write_hdr(path, w, h, sun):
         f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(px))
 
 
+def write_ppm(path, w, h, k):
+    """synthetic picture number k as binary PPM (stb_image sniffs the format from the content, so the
+    file may carry the .png / .jpg name a scene asks for)"""
+    px = bytearray()
+    for j in range(h):
+        for i in range(w):
+            px += bytes(((i * (5 + k) + j * 3 + 17 * k) % 256, (i * i + (7 + k) * j + 40) % 256,
+                         (128 + ((i ^ (3 * j)) + 29 * k) % 128) % 256))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h) + bytes(px))
+
+
+# scene 35 (pbr_texture_demo, scenes.cpp:1244-1300): albedo / roughness / metallic / normal maps
+PBR_TEXTURE_ASSETS = ["tex/oak/oak_veneer_01_diff_1k.png", "tex/oak/oak_veneer_01_rough_1k.png",
+                      "tex/oak/oak_veneer_01_nor_dx_1k.png", "tex/brick/red_brick_diff_1k.png",
+                      "tex/brick/red_brick_rough_1k.png", "tex/brick/red_brick_nor_dx_1k.png",
+                      "tex/rust/rusty_metal_04_diff_1k.png", "tex/rust/rusty_metal_04_rough_1k.png",
+                      "tex/rust/rusty_metal_04_metal_1k.png", "tex/rust/rusty_metal_04_nor_dx_1k.png"]
+
+
+def write_pbr_textures(td):
+    for k, rel in enumerate(PBR_TEXTURE_ASSETS):
+        write_ppm(os.path.join(td, rel), 24 + 2 * (k % 3), 20 + k, k)
+
+
 HDR_ASSETS = {24: ("brown_photostudio_02_4k.hdr", 32, 16, {(20, 4), (21, 4), (20, 5)}),
               26: ("rnl_probe.hdr", 16, 16, {(11, 5), (4, 9)})}
 
@@ -165,6 +191,27 @@ def main():
                 name = "img_scene%02d_i%d_64_spp16.f64" % (sid, integ)
                 cmd, info = run("render", sid, integ, 64, 16, 1, SCENE_SEED, os.path.join(GOLD, name), 8, cwd=td)
                 note(name, cmd, info, scene=sid, integrator=integ, width=64, height=info["height"], spp=16, seed=1)
+
+    # PBRMaterial with albedo / roughness / metallic / NORMAL maps from image files
+    # (scene 35); ten small synthetic pictures stand in for the absent tex/*.png assets.
+    with tempfile.TemporaryDirectory() as td:
+        write_pbr_textures(td)
+        what = "synthetic PPMs as tex/{oak,brick,rust}/*.png"
+        name = "scene35.rtrs"
+        cmd, info = run("dump-scene", 35, SCENE_SEED, os.path.join(GOLD, name), cwd=td)
+        note(name, cmd, info, raw_sha256=sha(os.path.join(GOLD, name)), asset=what)
+        name = "hits_scene35.bin"
+        cmd, info = run("hits", 35, SCENE_SEED, 768, 812, os.path.join(GOLD, name), cwd=td)
+        note(name, cmd, info, scene=35)
+        name = "materials_scene35.bin"
+        cmd, info = run("materials", 35, SCENE_SEED, 96, 4277, os.path.join(GOLD, name), cwd=td)
+        note(name, cmd, info, scene=35)
+        name = "li_scene35_i4.bin"
+        cmd, info = run("li", 35, 4, 64, 16, 1, SCENE_SEED, 768, os.path.join(GOLD, name), cwd=td)
+        note(name, cmd, info, scene=35, integrator=4, width=64, spp=16, seed=1)
+        name = "img_scene35_i4_64_spp16.f64"
+        cmd, info = run("render", 35, 4, 64, 16, 1, SCENE_SEED, os.path.join(GOLD, name), 8, cwd=td)
+        note(name, cmd, info, scene=35, integrator=4, width=64, height=info["height"], spp=16, seed=1)
 
     # one mid-size image of the headline config's scene
     name = "img_scene21_i4_128_spp32.f64"

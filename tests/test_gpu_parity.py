@@ -42,7 +42,7 @@ def _close(a, b, rtol):
     return np.abs(a - b) <= rtol * np.maximum(np.abs(b), 1e-300) + 1e-300
 
 
-@pytest.mark.parametrize("sid", [21, 23, 9, 1, 8])
+@pytest.mark.parametrize("sid", [21, 23, 9, 1, 8, 35])
 def test_unit_closest_hit(ctx, sid):
     _upload(ctx, sid)
     gold = G.records("hits_scene%02d.bin" % sid, A.HIT_DTYPE)
@@ -79,7 +79,7 @@ def test_unit_closest_hit(ctx, sid):
     assert np.array_equal(out["front_face"][both], gold["front_face"][both])
 
 
-@pytest.mark.parametrize("sid", [23, 9])
+@pytest.mark.parametrize("sid", [23, 9, 35])
 def test_unit_materials(ctx, sid):
     sc = _upload(ctx, sid)
     gold = G.records("materials_scene%02d.bin" % sid, A.MAT_DTYPE)
@@ -109,7 +109,7 @@ def test_unit_lights(ctx, sid):
         assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
 
 
-@pytest.mark.parametrize("sid,integ", [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4), (1, 1), (8, 1)])
+@pytest.mark.parametrize("sid,integ", [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4), (1, 1), (8, 1), (35, 4)])
 def test_li_records(ctx, sid, integ):
     """Per camera sample: radiance, RNG state at exit (pins the draw count), segment counts."""
     name = "li_scene%02d_i%d.bin" % (sid, integ)
@@ -134,7 +134,8 @@ def test_li_records(ctx, sid, integ):
 
 IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_scene21_i4_64_spp16.f64",
              "img_scene23_i4_64_spp16.f64", "img_scene09_i1_64_spp16.f64", "img_scene22_i4_64_spp16.f64",
-             "img_scene21_i4_128_spp32.f64", "img_scene01_i1_64_spp16.f64", "img_scene08_i1_64_spp16.f64"]
+             "img_scene21_i4_128_spp32.f64", "img_scene01_i1_64_spp16.f64", "img_scene08_i1_64_spp16.f64",
+             "img_scene35_i4_64_spp16.f64"]
 
 
 @pytest.mark.parametrize("name", IMG_CASES)

@@ -40,7 +40,7 @@ def test_sample_seed_never_zero():
     assert len(seen) > 250  # distinct streams
 
 
-@pytest.mark.parametrize("sid", [21, 23, 9, 4, 1, 8])
+@pytest.mark.parametrize("sid", [21, 23, 9, 4, 1, 8, 35])
 def test_closest_hit_vectors(sid):
     """hittable::hit on whole scenes: BVH order, wrappers, primitives, media RNG (SURVEY 3.4)."""
     sc = G.scene(sid)
@@ -64,7 +64,7 @@ def test_closest_hit_vectors(sid):
         assert np.any(gold["rng_in"] != gold["rng_out"])
 
 
-@pytest.mark.parametrize("sid", [23, 9])
+@pytest.mark.parametrize("sid", [23, 9, 35])
 def test_material_vectors(sid):
     """material::sample / eval / pdf / emitted (materials/material.h), textures, perlin."""
     sc = G.scene(sid)
@@ -81,7 +81,13 @@ def test_material_vectors(sid):
     for f in ("s_wi", "s_f", "s_pdf"):
         assert np.array_equal(_bits(out[f][ok]), _bits(gold[f][ok])), f
     assert np.array_equal(out["is_specular"][ok], gold["is_specular"][ok])
-    assert set(np.unique(types)) >= ({A.MAT_LAMBERTIAN, A.MAT_DIELECTRIC, A.MAT_DIFFUSE_LIGHT})
+    if sid == 35:  # PBRMaterial with image albedo / roughness / metallic and NORMAL maps (material.h:247-261)
+        pbr = sc.materials[sc.materials["type"] == A.MAT_PBR]
+        assert len(pbr) == 3 and np.all(pbr["tex"][:, 3] >= 0)
+        assert np.all(sc.textures["type"][pbr["tex"][:, 3]] == A.TEX_IMAGE) and np.all(sc.textures["a"][pbr["tex"][:, 3]] >= 0)
+        assert ((types == A.MAT_PBR) & (gold["sample_ok"] == 1)).sum() > 20
+    else:
+        assert set(np.unique(types)) >= ({A.MAT_LAMBERTIAN, A.MAT_DIELECTRIC, A.MAT_DIFFUSE_LIGHT})
 
 
 @pytest.mark.parametrize("sid", [21, 23, 15, 17, 18, 19, 24, 26])
@@ -109,7 +115,7 @@ def test_light_vectors(sid):
 
 LI_CASES = [(7, 1), (7, 4), (21, 4), (23, 4), (9, 1), (22, 4), (7, 0), (23, 2), (21, 3), (23, 3),
             (15, 4), (17, 4), (18, 4), (18, 3), (4, 1), (19, 4), (19, 3), (1, 1), (8, 1),
-            (24, 4), (24, 3), (26, 4), (26, 3)]
+            (24, 4), (24, 3), (26, 4), (26, 3), (35, 4)]
 
 
 @pytest.mark.parametrize("sid,integ", LI_CASES)
@@ -141,7 +147,7 @@ IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_
              "img_scene17_i4_64_spp16.f64", "img_scene18_i4_64_spp16.f64", "img_scene18_i3_64_spp16.f64",
              "img_scene04_i1_64_spp16.f64", "img_scene19_i4_64_spp16.f64", "img_scene19_i3_64_spp16.f64", "img_scene01_i1_64_spp16.f64",
              "img_scene08_i1_64_spp16.f64", "img_scene24_i4_64_spp16.f64", "img_scene24_i3_64_spp16.f64",
-             "img_scene26_i4_64_spp16.f64", "img_scene26_i3_64_spp16.f64"]
+             "img_scene26_i4_64_spp16.f64", "img_scene26_i3_64_spp16.f64", "img_scene35_i4_64_spp16.f64"]
 
 
 @pytest.mark.parametrize("name", IMG_CASES)
