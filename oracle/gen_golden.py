@@ -48,17 +48,92 @@ def write_ppm(path, w, h, k):
         f.write(b"P6\n%d %d\n255\n" % (w, h) + bytes(px))
 
 
-# scene 35 (pbr_texture_demo, scenes.cpp:1244-1300): albedo / roughness / metallic / normal maps
-PBR_TEXTURE_ASSETS = ["tex/oak/oak_veneer_01_diff_1k.png", "tex/oak/oak_veneer_01_rough_1k.png",
-                      "tex/oak/oak_veneer_01_nor_dx_1k.png", "tex/brick/red_brick_diff_1k.png",
-                      "tex/brick/red_brick_rough_1k.png", "tex/brick/red_brick_nor_dx_1k.png",
-                      "tex/rust/rusty_metal_04_diff_1k.png", "tex/rust/rusty_metal_04_rough_1k.png",
-                      "tex/rust/rusty_metal_04_metal_1k.png", "tex/rust/rusty_metal_04_nor_dx_1k.png"]
+def write_png(path, w, h, k, ctype, depth):
+    """synthetic picture number k as a PNG of the given colour type / bit depth, every row with another
+    filter type (0..4), so that a decoder has to implement all of them"""
+    import struct
+    import zlib
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    maxv = (1 << depth) - 1
+
+    def sample(i, j, ch):
+        v = (i * (5 + k + 2 * ch) + j * (3 + ch) + 17 * k + 40 * ch + ((i ^ (3 * j)) & 15)) % 256
+        return (v * maxv) // 255 if depth < 8 else (v * 257 if depth == 16 else v)
+
+    rows = []
+    for j in range(h):
+        if depth >= 8:
+            row = bytearray()
+            for i in range(w):
+                for ch in range(channels):
+                    v = sample(i, j, ch)
+                    row += struct.pack(">H", v) if depth == 16 else bytes((v,))
+        else:  # packed samples, most significant bits first
+            bits = 0
+            nb = 0
+            row = bytearray()
+            for i in range(w):
+                bits = (bits << depth) | sample(i, j, 0)
+                nb += depth
+                if nb == 8:
+                    row.append(bits)
+                    bits = nb = 0
+            if nb:
+                row.append(bits << (8 - nb))
+        rows.append(bytes(row))
+    bpp = max(1, channels * depth // 8)
+    raw = bytearray()
+    prev = bytes(len(rows[0]))
+    for j, row in enumerate(rows):
+        f = (j + k) % 5
+        out = bytearray()
+        for i, x in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if f == 0:
+                pred = 0
+            elif f == 1:
+                pred = a
+            elif f == 2:
+                pred = b
+            elif f == 3:
+                pred = (a + b) >> 1
+            else:
+                p_ = a + b - c
+                pa, pb, pc = abs(p_ - a), abs(p_ - b), abs(p_ - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out.append((x - pred) & 255)
+        raw += bytes((f,)) + bytes(out)
+        prev = row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if ctype == 3:
+        png += chunk(b"PLTE", bytes((((e * 7 + 3 * k) % 256) if c == 0 else ((e * 13 + 50) % 256) if c == 1 else
+                                     (255 - e) % 256) for e in range(1 << depth) for c in range(3)))
+    comp = zlib.compress(bytes(raw), 6)
+    half = len(comp) // 2
+    png += chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")  # split stream
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+# scene 35 (pbr_texture_demo, scenes.cpp:1244-1300): albedo / roughness / metallic / normal maps as PNG files of
+# every colour type the decoders must handle: (path, colour type, bit depth)
+PBR_TEXTURE_ASSETS = [("tex/oak/oak_veneer_01_diff_1k.png", 2, 8), ("tex/oak/oak_veneer_01_rough_1k.png", 0, 8),
+                      ("tex/oak/oak_veneer_01_nor_dx_1k.png", 6, 8), ("tex/brick/red_brick_diff_1k.png", 3, 8),
+                      ("tex/brick/red_brick_rough_1k.png", 0, 4), ("tex/brick/red_brick_nor_dx_1k.png", 2, 16),
+                      ("tex/rust/rusty_metal_04_diff_1k.png", 2, 8), ("tex/rust/rusty_metal_04_rough_1k.png", 4, 8),
+                      ("tex/rust/rusty_metal_04_metal_1k.png", 3, 4), ("tex/rust/rusty_metal_04_nor_dx_1k.png", 2, 8)]
 
 
 def write_pbr_textures(td):
-    for k, rel in enumerate(PBR_TEXTURE_ASSETS):
-        write_ppm(os.path.join(td, rel), 24 + 2 * (k % 3), 20 + k, k)
+    for k, (rel, ctype, depth) in enumerate(PBR_TEXTURE_ASSETS):
+        write_png(os.path.join(td, rel), 24 + 2 * (k % 3), 20 + k, k, ctype, depth)
 
 
 HDR_ASSETS = {24: ("brown_photostudio_02_4k.hdr", 32, 16, {(20, 4), (21, 4), (20, 5)}),
@@ -196,7 +271,7 @@ def main():
     # (scene 35); ten small synthetic pictures stand in for the absent tex/*.png assets.
     with tempfile.TemporaryDirectory() as td:
         write_pbr_textures(td)
-        what = "synthetic PPMs as tex/{oak,brick,rust}/*.png"
+        what = "synthetic PNGs (grey, grey+alpha, RGB, RGBA, palette; 4/8/16 bit) as tex/{oak,brick,rust}/*.png"
         name = "scene35.rtrs"
         cmd, info = run("dump-scene", 35, SCENE_SEED, os.path.join(GOLD, name), cwd=td)
         note(name, cmd, info, raw_sha256=sha(os.path.join(GOLD, name)), asset=what)

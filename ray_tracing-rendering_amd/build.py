@@ -52,7 +52,7 @@ def build_host(force=False):
     out = os.path.join(HERE, "librtr_host.so")
     if not force and not _newer(out, _sources(HOST, (".cpp", ".h"))):
         return out
-    cmd = ["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I" + INC, "-I" + HOST, src, "-o", out]
+    cmd = ["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I" + INC, "-I" + HOST, src, "-o", out, "-lz"]
     subprocess.run(cmd, check=True)
     return out
 
@@ -68,7 +68,7 @@ def build_cli(force=False):
         return out
     cmd = ["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-I" + INC, "-I" + HOST, src,
            os.path.join(HOST, "rtr_host.cpp"), "-L" + HERE, "-lrtr_hip", "-Wl,-rpath,$ORIGIN",
-           "-Wl,--allow-shlib-undefined", "-o", out]
+           "-Wl,--allow-shlib-undefined", "-lz", "-o", out]
     subprocess.run(cmd, check=True)
     return out
 

@@ -829,13 +829,17 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
     return any;
 }
 
-template <int TRAV>
+/* UV_POSSIBLE = false: the caller's material set has no texture that reads (u,v) (lean / quadlit kernels) */
+template <int TRAV, bool UV_POSSIBLE = true>
 __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real time, Hit& rec, uint32_t& rng,
                                              const Stack st, Real tmin = 0.001, Real tmax = RT_INF) {
     if (TRAV == RT_TRAV_FAST) {
         int ref, inst;
         if (!trace_fast<false>(sc, 0, sc.n_finst, o, d, time, tmin, tmax, ref, inst, st, 0)) return false;
-        fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec); /* scenes whose textures read (u,v) use the reference-order traversal */
+        if (UV_POSSIBLE && sc.needs_uv)
+            fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
+        else
+            fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec);
         return true;
     }
     if (TRAV == RT_TRAV_PROGRAM) {
@@ -847,7 +851,7 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
             rec.n = mk(1, 0, 0);
             rec.front = true;
             rec.mat = as_const(sc.fstep)[med].mat;
-        } else if (sc.needs_uv) {
+        } else if (UV_POSSIBLE && sc.needs_uv) {
             fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
         } else {
             fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec);
@@ -906,7 +910,7 @@ RT_DEV Real perlin_turb(const rtr_perlin& pn, V3 p) { /* perlin.h:41-54 */
 
 /* ---- materials/texture.h:11-162 ----------------------------------------------------------------- */
 /* checker / noise / image textures */
-__device__ inline V3 tex_value_slow(const DScene& sc, int ix, Real u, Real v, V3 p) {
+__device__ __forceinline__ V3 tex_value_slow(const DScene& sc, int ix, Real u, Real v, V3 p) {
     /* checker textures nest (texture.h:60-66); unrolled to a bounded loop instead of recursion */
     for (int guard = 0; guard < 8; ++guard) {
         const rtr_texture& t = sc.textures[ix];
@@ -942,8 +946,9 @@ __device__ inline V3 tex_value_slow(const DScene& sc, int ix, Real u, Real v, V3
  * Cook-Torrance / pow() / perlin out of their register budget.  RT_MS_FULL handles everything. */
 #define RT_MS_LEAN 0
 #define RT_MS_FULL 1
-#define RT_MS_QUADLIT 2 /* every material, but only QuadLights: keeps the delta / environment light code
-                           (binary searches, sin / cos / acos / atan2) out of e.g. scene 23's kernel */
+#define RT_MS_QUADLIT 2 /* every material, but only QuadLights and no texture that reads (u,v): keeps the delta /
+                           environment light code (binary searches, sin / cos / acos / atan2) and the (u,v)
+                           reconstruction out of e.g. scene 23's kernel */
 
 template <int MS = RT_MS_FULL>
 RT_DEV V3 tex_value(const DScene& sc, int ix, Real u, Real v, V3 p) {
@@ -1017,7 +1022,7 @@ RT_DEV V3 pbr_normal(const DScene& sc, const rtr_material& m, const Hit& rec) { 
     }
     return N;
 }
-__device__ inline Real pbr_pdf(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
+__device__ __forceinline__ Real pbr_pdf(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
     /* material.h:305-340 */
     V3 N = pbr_normal(sc, m, rec);
     if (dot(N, wi) <= 0) return 0;
@@ -1031,7 +1036,7 @@ __device__ inline Real pbr_pdf(const DScene& sc, const rtr_material& m, const Hi
     Real pdf_spec = (D * NdotH) / (4.0 * HdotV + 0.0001);
     return 0.5 * pdf_diff + 0.5 * pdf_spec;
 }
-__device__ inline V3 pbr_eval(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
+__device__ __forceinline__ V3 pbr_eval(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
     /* material.h:342-396 */
     V3 N = pbr_normal(sc, m, rec);
     Real NdotL = dot(N, wi);
@@ -1078,7 +1083,7 @@ RT_DEV V3 mat_emitted_legacy(const DScene& sc, const Hit& rec) {
 }
 
 /* PBRMaterial::sample (material.h:245-303), out of line like pbr_eval / pbr_pdf */
-__device__ inline bool pbr_sample(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, BSDFSample& s,
+__device__ __forceinline__ bool pbr_sample(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, BSDFSample& s,
                                         uint32_t& rng) {
     {
         V3 N = pbr_normal(sc, m, rec);

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES :
                 Hit rec;
                 rec.u = 0, rec.v = 0;
                 pk.set(PK_NCLOSEST, pk.get(PK_NCLOSEST) + 1.0);
-                const bool hit_any = cast_closest<TRAV>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st);
+                const bool hit_any = cast_closest<TRAV, MS == RT_MS_FULL>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st);
                 RTR_CLK(clk_closest);
                 if (!hit_any) {
                     pk.set3(PK_L, add(pk.get3(PK_L), miss_radiance<INTEG, MS>(sc, pk.get3(PK_THR), ps.ro, ps.rd, ps.depth,

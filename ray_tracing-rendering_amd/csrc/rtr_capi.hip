@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,6 +44,9 @@ struct rtr_context {
     bool force_exact = false;
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
     bool quad_lights_only = false;
+    /* a moving_sphere (its hit() writes no u,v: the record keeps those of an earlier, farther hit of the
+     * reference's walk) carries a material that reads (u,v): only the reference-order walk reproduces that */
+    bool uv_order_dependent = false;
     int n_material_types = 0;
     /* per-render workspace */
     DevBuf b_tiles, b_partial, b_stats, b_cancel, b_test;
@@ -315,8 +319,8 @@ int pick_trav(const rtr_context* c, int flags) {
     if (c->info.has_media)
         return c->info.program_steps > 0 && !c->force_exact && !(flags & RTR_FLAG_REFERENCE_ORDER) ? RT_TRAV_PROGRAM
                                                                                                      : RT_TRAV_MEDIA;
-    if (!c->info.fast_ok || c->info.needs_uv || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER))
-        return RT_TRAV_EXACT; /* the compiled path carries no (u,v) */
+    if (!c->info.fast_ok || c->uv_order_dependent || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER))
+        return RT_TRAV_EXACT;
     return RT_TRAV_FAST;
 }
 size_t stack_bytes(const rtr_context* c, int trav) {
@@ -339,7 +343,7 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
     const DScene* dsc = static_cast<const DScene*>(c->b_dscene.p);
     const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
     const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
-    const bool quadlit = c->quad_lights_only;
+    const bool quadlit = c->quad_lights_only && !c->info.needs_uv;
 #define RTR_LAUNCH(I, T, M)                                                                        \
     do {                                                                                           \
         int rc_ = set_lds(c, k_mega<I, T, M>, lds);                                                \
@@ -599,6 +603,23 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
         if (m.type != RTR_MAT_LAMBERTIAN && m.type != RTR_MAT_DIFFUSE_LIGHT) c->lean_materials = false;
         else if (s->textures[m.tex[0]].type != RTR_TEX_SOLID) c->lean_materials = false;
     }
+    c->uv_order_dependent = false;
+    if (info.needs_uv) {
+        std::function<bool(int, int)> tex_reads_uv = [&](int t, int guard) {
+            if (t < 0 || guard > 8) return false;
+            const rtr_texture& x = s->textures[t];
+            if (x.type == RTR_TEX_IMAGE) return x.a >= 0;
+            if (x.type == RTR_TEX_CHECKER) return tex_reads_uv(x.a, guard + 1) || tex_reads_uv(x.b, guard + 1);
+            return false;
+        };
+        for (int k = 0; k < s->n_nodes; ++k) {
+            if (s->nodes[k].type != RTR_NODE_MOVING_SPHERE) continue;
+            const rtr_material& m = s->materials[s->nodes[k].a];
+            const int n_tex = m.type == RTR_MAT_PBR ? 4 : (m.type == RTR_MAT_METAL || m.type == RTR_MAT_DIELECTRIC ? 0 : 1);
+            for (int q = 0; q < n_tex; ++q)
+                if (tex_reads_uv(m.tex[q], 0)) c->uv_order_dependent = true;
+        }
+    }
     if ((rc = upload(c, c->b_dscene, &c->ds, sizeof(DScene)))) return rc;
     c->has_scene = true;
     return RTR_OK;
@@ -655,7 +676,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
         const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
-        rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean, c->quad_lights_only,
+        rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean, c->quad_lights_only && !c->info.needs_uv,
                               !lean && c->n_material_types > 1, trav, stack_bytes(c, trav), P, p->integrator, d_rgb,
                               row_stride, c->stream, &c->cancel_requested, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;

@@ -26,8 +26,20 @@
 #include "rtr_hip.h"
 #include "rtr_scene_io.h"
 
+#if defined(__has_include)
+#if __has_include(<zlib.h>) && !defined(RTR_NO_ZLIB)
+#include <zlib.h> /* PNG textures; link with -lz (define RTR_NO_ZLIB to build without) */
+#define RTR_HAVE_ZLIB 1
+#endif
+#endif
+#ifndef RTR_HAVE_ZLIB
+#define RTR_HAVE_ZLIB 0
+#endif
+
 #include <algorithm>
+#include <cctype>
 #include <cmath>
+#include <cstring>
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
@@ -1020,16 +1032,155 @@ inline int noise_texture::rtr_flatten(rtr::Flattener& f) const {
     f.out.perlin.push_back(p);
     return 0;
 }
-inline image_texture::image_texture(const char* filename) {
-    FILE* fp = filename ? std::fopen(filename, "rb") : nullptr;
-    int w = 0, h = 0, maxv = 0;
-    if (fp && std::fscanf(fp, "P6 %d %d %d", &w, &h, &maxv) == 3 && maxv == 255 && w > 0 && h > 0 && std::fgetc(fp) != EOF) {
-        data.resize((size_t)w * h * 3);
-        if (std::fread(data.data(), 1, data.size(), fp) == data.size()) width = w, height = h;
-        else data.clear();
+/* image files: binary PPM always; PNG (8/16-bit, grey / grey+alpha / RGB / RGBA / palette, non-interlaced)
+ * when zlib is there.  Texels come out as the 3 x 8-bit RGB stb_image hands the reference for
+ * req_comp = 3 (materials/texture.h:96-100): grey replicated, alpha dropped, 16-bit samples >> 8,
+ * 1/2/4-bit grey scaled to 0..255.  JPEG and interlaced PNG are not decoded: such a file counts as
+ * missing (cyan fallback, texture.h:101-105). */
+namespace rtr {
+inline bool read_file(const char* path, std::vector<unsigned char>& out) {
+    FILE* fp = path ? std::fopen(path, "rb") : nullptr;
+    if (!fp) return false;
+    unsigned char buf[65536];
+    size_t r;
+    while ((r = std::fread(buf, 1, sizeof buf, fp)) > 0) out.insert(out.end(), buf, buf + r);
+    std::fclose(fp);
+    return true;
+}
+inline bool decode_ppm(const std::vector<unsigned char>& file, std::vector<unsigned char>& rgb, int& w, int& h) {
+    if (file.size() < 2 || file[0] != 'P' || file[1] != '6') return false;
+    size_t pos = 2;
+    int vals[3];
+    for (int k = 0; k < 3; ++k) {
+        while (pos < file.size() && (std::isspace(file[pos]) || file[pos] == '#')) {
+            if (file[pos] == '#')
+                while (pos < file.size() && file[pos] != '\n') ++pos;
+            else
+                ++pos;
+        }
+        long v = 0;
+        bool any = false;
+        while (pos < file.size() && std::isdigit(file[pos])) v = v * 10 + (file[pos++] - '0'), any = true;
+        if (!any || v <= 0 || v > 65536) return false;
+        vals[k] = (int)v;
     }
-    if (fp) std::fclose(fp);
-    if (data.empty()) std::cerr << "ERROR: Could not load texture image file '" << (filename ? filename : "") << "'.\n";
+    if (vals[2] != 255 || pos >= file.size()) return false;
+    ++pos; /* the single whitespace after maxval */
+    const size_t need = (size_t)vals[0] * vals[1] * 3;
+    if (file.size() - pos < need) return false;
+    rgb.assign(file.begin() + pos, file.begin() + pos + need);
+    w = vals[0], h = vals[1];
+    return true;
+}
+#if RTR_HAVE_ZLIB
+inline bool decode_png(const std::vector<unsigned char>& file, std::vector<unsigned char>& rgb, int& w, int& h) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) return false;
+    auto be32 = [&](size_t o) { return ((uint32_t)file[o] << 24) | (file[o + 1] << 16) | (file[o + 2] << 8) | file[o + 3]; };
+    size_t pos = 8;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    w = h = 0;
+    while (pos + 12 <= file.size()) {
+        const uint32_t len = be32(pos);
+        const unsigned char* tag = &file[pos + 4];
+        if (pos + 12 + (size_t)len > file.size()) return false;
+        const unsigned char* d = &file[pos + 8];
+        if (!std::memcmp(tag, "IHDR", 4) && len == 13) {
+            w = (int)be32(pos + 8), h = (int)be32(pos + 12);
+            depth = d[8], ctype = d[9], interlace = d[12];
+        } else if (!std::memcmp(tag, "PLTE", 4)) {
+            plte.assign(d, d + len);
+        } else if (!std::memcmp(tag, "IDAT", 4)) {
+            idat.insert(idat.end(), d, d + len);
+        } else if (!std::memcmp(tag, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + (size_t)len;
+    }
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || interlace != 0) return false;
+    int channels;
+    switch (ctype) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: return false;
+    }
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
+    if (ctype == 3 && depth == 16) return false;
+    const size_t bpp_bits = (size_t)channels * depth, stride = ((size_t)w * bpp_bits + 7) / 8;
+    const size_t bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1; /* filter distance in bytes */
+    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
+    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    rgb.resize((size_t)w * h * 3);
+    for (int j = 0; j < h; ++j) {
+        const unsigned char* line = &raw[(stride + 1) * (size_t)j];
+        const int filter = line[0];
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred;
+            switch (filter) {
+            case 0: pred = 0; break;
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) >> 1; break;
+            case 4: {
+                const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                break;
+            }
+            default: return false;
+            }
+            cur[i] = (unsigned char)(line[1 + i] + pred);
+        }
+        for (int i = 0; i < w; ++i) {
+            unsigned char px[4] = {0, 0, 0, 0};
+            for (int ch = 0; ch < channels; ++ch) {
+                unsigned v;
+                if (depth == 8) {
+                    v = cur[(size_t)i * channels + ch];
+                } else if (depth == 16) {
+                    v = cur[((size_t)i * channels + ch) * 2]; /* high byte = sample >> 8 */
+                } else {
+                    const size_t bit = (size_t)i * depth;
+                    v = (cur[bit / 8] >> (8 - depth - bit % 8)) & ((1u << depth) - 1);
+                    if (ctype == 0) v *= depth == 1 ? 255 : (depth == 2 ? 85 : 17);
+                }
+                px[ch] = (unsigned char)v;
+            }
+            unsigned char* o = &rgb[((size_t)j * w + i) * 3];
+            if (ctype == 3) {
+                const size_t e = (size_t)px[0] * 3;
+                if (e + 3 > plte.size()) return false;
+                o[0] = plte[e], o[1] = plte[e + 1], o[2] = plte[e + 2];
+            } else if (channels <= 2) {
+                o[0] = o[1] = o[2] = px[0];
+            } else {
+                o[0] = px[0], o[1] = px[1], o[2] = px[2];
+            }
+        }
+        prev.swap(cur);
+    }
+    return true;
+}
+#endif
+} // namespace rtr
+
+inline image_texture::image_texture(const char* filename) {
+    std::vector<unsigned char> file;
+    bool ok = rtr::read_file(filename, file) && rtr::decode_ppm(file, data, width, height);
+#if RTR_HAVE_ZLIB
+    if (!ok && !file.empty()) ok = rtr::decode_png(file, data, width, height);
+#endif
+    if (!ok) {
+        data.clear();
+        width = height = 0;
+        std::cerr << "ERROR: Could not load texture image file '" << (filename ? filename : "") << "'.\n";
+    }
 }
 inline int image_texture::rtr_flatten(rtr::Flattener& f) const {
     rtr_texture& r = f.cur(this);

@@ -210,7 +210,7 @@ def test_properties_at_full_size(ctx, pipeline):
     assert abs(other.mean() - full.mean()) <= 0.05 * full.mean()
 
 
-@pytest.mark.parametrize("sid", [7, 21, 23, 1])
+@pytest.mark.parametrize("sid", [7, 21, 23, 1, 4, 35])
 def test_compiled_scene_equals_reference_order(ctx, sid):
     """Scenes without media: the order-free compiled-scene traversal (default) and the
     reference-order traversal (RTR_FLAG_REFERENCE_ORDER) must agree bit for bit."""
@@ -237,7 +237,7 @@ def test_compiled_scene_equals_reference_order(ctx, sid):
     for f in ("u", "v"):
         assert np.array_equal(_bits(fast[f][sets_uv]), _bits(exact[f][sets_uv])), f
     for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
-        integ = 1 if sid in (7, 1) else 4
+        integ = 1 if sid in (7, 1, 4) else 4  # 4 and 35: image textures, (u,v) rebuilt after the order-free cast
         a = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe))
         sa = ctx.stats()
         b = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe,
@@ -366,8 +366,8 @@ def test_delta_and_environment_lights(ctx, sid):
 
 def test_image_texture(ctx):
     """image_texture with real texels (scene 4 + synthetic picture): (u,v) from
-    acos/atan2 on the sphere, nearest-texel fetch.  The compiled path carries no (u,v), so this
-    scene runs the reference-order traversal."""
+    acos/atan2 on the sphere, nearest-texel fetch.  Runs the compiled traversal, which rebuilds
+    (u,v) for the winning primitive (test_compiled_scene_equals_reference_order covers both)."""
     sc = _upload(ctx, 4)
     assert G.rtr.native.validate_scene(sc)["needs_uv"]
     gold = G.records("hits_scene04.bin", A.HIT_DTYPE)

@@ -66,10 +66,7 @@ def test_environment_map_scenes_drop_in(sid):
     """EnvironmentLight of the host layer (own RGBE reader, Distribution2D tables) on the synthetic
     maps the goldens were made with: the flattened scene equals the one walked out of the
     reference's objects (stb_image texels, its Distribution2D), byte for byte."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(G.ROOT, "oracle", "gen_golden.py"))
-    gen = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gen)
+    gen = _gen_golden_module()
     fname, w, h, sun = gen.HDR_ASSETS[sid]
     with tempfile.TemporaryDirectory() as td:
         gen.write_hdr(os.path.join(td, fname), w, h, sun)
@@ -77,6 +74,31 @@ def test_environment_map_scenes_drop_in(sid):
         r = subprocess.run([DROPIN, str(sid), "12345", out], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=td)
         assert r.returncode == 0, r.stdout
         assert open(out, "rb").read() == G.scene(sid).to_bytes()
+
+
+def _gen_golden_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(G.ROOT, "oracle", "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_scenes is built only where the reference is")
+def test_png_textured_pbr_scene_drops_in():
+    """Scene 35 (PBRMaterial with image albedo / roughness / metallic / normal maps): the host layer's
+    own PNG decoder (zlib inflate + the five row filters; grey, grey+alpha, RGB, RGBA and palette
+    images of 4, 8 and 16 bits) yields the texels stb_image gave the reference -- the flattened
+    scene is byte-identical to the golden walked out of the reference's objects."""
+    gen = _gen_golden_module()
+    with tempfile.TemporaryDirectory() as td:
+        gen.write_pbr_textures(td)
+        out = os.path.join(td, "s.rtrs")
+        r = subprocess.run([DROPIN, "35", "12345", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=td)
+        assert r.returncode == 0, r.stdout
+        assert b"Could not load" not in r.stderr
+        sc = rtr.Scene.load(out)
+        assert len(sc.images) == 10 and sc.to_bytes() == G.scene(35).to_bytes()
 
 
 def _rle_scanline(row):
