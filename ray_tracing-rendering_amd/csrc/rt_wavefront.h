@@ -156,7 +156,9 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_finish(const WfState S, const Re
     }
 }
 
-template <int TRAV, bool SORT>
+/* RICH = false: scenes lit by QuadLights only whose textures read no (u,v) (rtr_upload_scene
+ * decides): no environment-light code on the miss branch, no (u,v) reconstruction */
+template <int TRAV, bool SORT, bool RICH>
 __global__ void __launch_bounds__(RTR_BLOCK, 4) wf_extend(const DScene* __restrict__ scp, const WfState S,
                                                           const RenderK P, const int parity) {
     extern __shared__ int lds_stack[];
@@ -216,12 +218,12 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4) wf_extend(const DScene* __restri
             Hit rec;
             rec.u = 0, rec.v = 0;
             S.n_closest[slot] += 1;
-            if (!cast_closest<TRAV>(sc, ro, rd, tm, rec, rng, st)) {
+            if (!cast_closest<TRAV, RICH>(sc, ro, rd, tm, rec, rng, st)) {
                 /* mis_path_integrator.h:37-67, rr_path_integrator.h:31-33 */
                 const V3 thr = ldv(S.tx, S.ty, S.tz, slot);
                 V3 add_l;
                 if (P.integrator == RTR_INTEGRATOR_MIS)
-                    add_l = miss_radiance<RTR_INTEGRATOR_MIS>(sc, thr, ro, rd, flags >> 8, (flags & WF_SPEC) != 0,
+                    add_l = miss_radiance<RTR_INTEGRATOR_MIS, RICH ? RT_MS_FULL : RT_MS_QUADLIT>(sc, thr, ro, rd, flags >> 8, (flags & WF_SPEC) != 0,
                                                               S.pdf[slot]);
                 else
                     add_l = mul(thr, ld3(sc.background));
@@ -461,15 +463,22 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
     hipLaunchKernelGGL(wf_init, grid, block, 0, stream, S, P);
     ++n_launch;
 
-#define WF_EXTEND(T)                                                                                     \
+#define WF_EXTEND_R(T, R)                                                                                \
     do {                                                                                                 \
-        if ((rc = wf_lds_attr(wf_extend<T, true>, lds, err)) || (rc = wf_lds_attr(wf_extend<T, false>, lds, err))) \
+        if ((rc = wf_lds_attr(wf_extend<T, true, R>, lds, err)) || (rc = wf_lds_attr(wf_extend<T, false, R>, lds, err))) \
             return rc;                                                                                   \
         if (sort)                                                                                        \
-            hipLaunchKernelGGL((wf_extend<T, true>), grid, block, lds, stream, sc, S, P, par);           \
+            hipLaunchKernelGGL((wf_extend<T, true, R>), grid, block, lds, stream, sc, S, P, par);        \
         else                                                                                             \
-            hipLaunchKernelGGL((wf_extend<T, false>), grid, block, lds, stream, sc, S, P, par);          \
+            hipLaunchKernelGGL((wf_extend<T, false, R>), grid, block, lds, stream, sc, S, P, par);       \
         ++n_launch;                                                                                      \
+    } while (0)
+#define WF_EXTEND(T)                \
+    do {                            \
+        if (lean || quadlit)        \
+            WF_EXTEND_R(T, false);  \
+        else                        \
+            WF_EXTEND_R(T, true);   \
     } while (0)
 #define WF_SHADE(I, PH, M)                                                                               \
     do {                                                                                                 \
@@ -495,9 +504,9 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
             if (trav == RT_TRAV_FAST)
                 WF_EXTEND(RT_TRAV_FAST);
             else if (trav == RT_TRAV_PROGRAM)
-                WF_EXTEND(RT_TRAV_PROGRAM);
+                WF_EXTEND_R(RT_TRAV_PROGRAM, true);
             else if (media)
-                WF_EXTEND(RT_TRAV_MEDIA);
+                WF_EXTEND_R(RT_TRAV_MEDIA, true);
             else
                 WF_EXTEND(RT_TRAV_EXACT);
             if (!mis) {
@@ -542,6 +551,7 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
         }
     }
 #undef WF_EXTEND
+#undef WF_EXTEND_R
 #undef WF_SHADE
 #undef WF_CONNECT
     hipLaunchKernelGGL(wf_finish, grid, block, 0, stream, S, P);
