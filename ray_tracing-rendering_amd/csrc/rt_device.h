@@ -419,7 +419,7 @@ RT_DEV void wrapper_enter(int type, const double* f, V3& o, V3& d) {
 }
 
 /* defined below (order-free traversal of compiled sub-scenes) */
-template <bool ANY>
+template <bool ANY, bool TREES = true>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
                                            Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
                                            const Stack st, const int sp0);
@@ -640,8 +640,10 @@ RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real 
 }
 
 /* Closest hit (ANY = false) or first hit found (ANY = true: shadow rays only need existence).
- * Returns the reference and instance of the hit; `tmax` returns its t. */
-template <bool ANY>
+ * Returns the reference and instance of the hit; `tmax` returns its t.  TREES = false: the caller
+ * knows that no instance of the scene has a box tree (RT_TRAV_FLAT), which keeps that code and
+ * its registers out of the kernels of small scenes (the Cornell box: 122 VGPRs, no spills). */
+template <bool ANY, bool TREES>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
                                            Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
                                            const Stack st, const int sp0) {
@@ -666,7 +668,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                 wrapper_enter(x.type, x.f, lo, ld);
             }
         }
-        if (I.bvh_root < 0) {
+        if (!TREES || I.bvh_root < 0) {
             const int r0 = I.ref_first, r1 = r0 + I.n_ref;
             for (int r = r0; r < r1; ++r) {
                 Real t;
@@ -777,6 +779,7 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
 #define RT_TRAV_MEDIA 1
 #define RT_TRAV_FAST 2
 #define RT_TRAV_PROGRAM 3 /* scenes with media: the step program (struct FStep) */
+#define RT_TRAV_FLAT 4    /* compiled scene none of whose instances has a box tree */
 
 /* Run the ray-cast program over [tmin, tmax].  Returns whether anything was hit; then `tmax` is
  * the hit's t and either `med` >= 0 (the step of the medium that scattered the ray) or
@@ -833,9 +836,9 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
 template <int TRAV, bool UV_POSSIBLE = true>
 __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real time, Hit& rec, uint32_t& rng,
                                              const Stack st, Real tmin = 0.001, Real tmax = RT_INF) {
-    if (TRAV == RT_TRAV_FAST) {
+    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT) {
         int ref, inst;
-        if (!trace_fast<false>(sc, 0, sc.n_finst, o, d, time, tmin, tmax, ref, inst, st, 0)) return false;
+        if (!trace_fast<false, TRAV == RT_TRAV_FAST>(sc, 0, sc.n_finst, o, d, time, tmin, tmax, ref, inst, st, 0)) return false;
         if (UV_POSSIBLE && sc.needs_uv)
             fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
         else
@@ -862,9 +865,9 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
 }
 template <int TRAV>
 __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real tmax, uint32_t& rng, const Stack st) {
-    if (TRAV == RT_TRAV_FAST) {
+    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT) {
         int ref, inst;
-        return trace_fast<true>(sc, 0, sc.n_finst, o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
+        return trace_fast<true, TRAV == RT_TRAV_FAST>(sc, 0, sc.n_finst, o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
     }
     if (TRAV == RT_TRAV_PROGRAM) { /* the media behind a blocker still draw */
         int ref, inst, med;

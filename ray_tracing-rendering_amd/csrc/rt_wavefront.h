@@ -501,7 +501,9 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
     for (;;) {
         for (int b = 0; b < check; ++b, ++iter) {
             const int par = iter & 1;
-            if (trav == RT_TRAV_FAST)
+            if (trav == RT_TRAV_FLAT)
+                WF_EXTEND(RT_TRAV_FLAT);
+            else if (trav == RT_TRAV_FAST)
                 WF_EXTEND(RT_TRAV_FAST);
             else if (trav == RT_TRAV_PROGRAM)
                 WF_EXTEND_R(RT_TRAV_PROGRAM, true);
@@ -522,7 +524,9 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
                 else
                     WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_FULL);
                 if (has_lights) {
-                    if (trav == RT_TRAV_FAST)
+                    if (trav == RT_TRAV_FLAT)
+                        WF_CONNECT(RT_TRAV_FLAT);
+                    else if (trav == RT_TRAV_FAST)
                         WF_CONNECT(RT_TRAV_FAST);
                     else
                         WF_CONNECT(RT_TRAV_EXACT);

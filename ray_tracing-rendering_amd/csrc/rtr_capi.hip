@@ -44,6 +44,7 @@ struct rtr_context {
     bool force_exact = false;
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
     bool quad_lights_only = false;
+    bool flat_scene = false; /* compiled scene without box trees */
     /* a moving_sphere (its hit() writes no u,v: the record keeps those of an earlier, farther hit of the
      * reference's walk) carries a material that reads (u,v): only the reference-order walk reproduces that */
     bool uv_order_dependent = false;
@@ -321,10 +322,10 @@ int pick_trav(const rtr_context* c, int flags) {
                                                                                                      : RT_TRAV_MEDIA;
     if (!c->info.fast_ok || c->uv_order_dependent || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER))
         return RT_TRAV_EXACT;
-    return RT_TRAV_FAST;
+    return c->flat_scene ? RT_TRAV_FLAT : RT_TRAV_FAST;
 }
 size_t stack_bytes(const rtr_context* c, int trav) {
-    const int words = trav == RT_TRAV_FAST || trav == RT_TRAV_PROGRAM ? c->fast_stack_words
+    const int words = trav == RT_TRAV_FAST || trav == RT_TRAV_FLAT || trav == RT_TRAV_PROGRAM ? c->fast_stack_words
                                                                       : c->info.stack_words + c->walk_extra_words;
     return (size_t)words * RTR_BLOCK * sizeof(int);
 }
@@ -337,7 +338,9 @@ int set_lds(rtr_context* c, K kernel, size_t bytes) {
     return RTR_OK;
 }
 
-int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
+int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in) {
+    /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
+    const int trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
     const int stack_words = (int)(stack_bytes(c, trav) / (RTR_BLOCK * sizeof(int)));
     const size_t lds = stack_bytes(c, trav) + (size_t)RT_PARK_WORDS * RTR_BLOCK * sizeof(double);
     const DScene* dsc = static_cast<const DScene*>(c->b_dscene.p);
@@ -353,7 +356,14 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav) {
 /* FULLQ = the variant for "every material, QuadLights only" (the RR integrator has no light code) */
 #define RTR_LAUNCH_T(I, FULLQ)                                              \
     do {                                                                    \
-        if (trav == RT_TRAV_FAST) {                                         \
+        if (trav == RT_TRAV_FLAT) {                                         \
+            if (lean)                                                       \
+                RTR_LAUNCH(I, RT_TRAV_FLAT, RT_MS_LEAN);                    \
+            else if (quadlit)                                               \
+                RTR_LAUNCH(I, RT_TRAV_FLAT, FULLQ);                         \
+            else                                                            \
+                RTR_LAUNCH(I, RT_TRAV_FLAT, RT_MS_FULL);                    \
+        } else if (trav == RT_TRAV_FAST) {                                  \
             if (lean)                                                       \
                 RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_LEAN);                    \
             else if (quadlit)                                               \
@@ -561,6 +571,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
         if ((rc = upload(c, c->b_fprim, prims.data(), sizeof(rtr_node) * prims.size()))) return rc;
     }
     c->fast_stack_words = cs.stack_words;
+    c->flat_scene = cs.ok && cs.bvh.empty();
     c->walk_extra_words = cs.n_compiled_subtrees ? cs.stack_words : 0;
     DScene& d = c->ds;
     d.finst = static_cast<const FInst*>(c->b_finst.p);
@@ -778,7 +789,8 @@ int rtr_test_hits(rtr_context* c, rtr_hit_record* recs, int64_t n) {
     DScene ds = c->ds;
     ds.needs_uv = 1; /* the vectors pin u,v although no flattened texture of these scenes reads them */
     auto* d = static_cast<rtr_hit_record*>(c->b_test.p);
-    const int trav = pick_trav(c, 0);
+    int trav = pick_trav(c, 0);
+    if (trav == RT_TRAV_FLAT) trav = RT_TRAV_FAST; /* same results; one test kernel for both */
     const size_t lds = stack_bytes(c, trav);
     if (trav == RT_TRAV_FAST) {
         if ((rc = set_lds(c, k_test_hits<RT_TRAV_FAST>, lds))) return rc;
@@ -827,7 +839,8 @@ int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs,
     P.spp = p->spp, P.max_depth = p->max_depth, P.rr_start = p->rr_start_depth;
     P.seed = p->seed;
     auto* d = static_cast<rtr_li_record*>(c->b_test.p);
-    const int trav = pick_trav(c, p->flags);
+    int trav = pick_trav(c, p->flags);
+    if (trav == RT_TRAV_FLAT) trav = RT_TRAV_FAST;
     const size_t lds = stack_bytes(c, trav);
 #define RTR_LAUNCH(I, T)                                                                                        \
     do {                                                                                                        \
