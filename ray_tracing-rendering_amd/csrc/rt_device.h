@@ -322,15 +322,8 @@ RT_DEV void sphere_uv(V3 p, Real& u, Real& v) { /* geometry/sphere.h:24-30 */
 
 /* ---- primitive tests shared by both traversals ------------------------------------------------ */
 /* x?_rect::hit (geometry/aarect.h:79-135): t and the in-plane coordinates (a, b) */
-RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real tmax, Real& t, Real& a, Real& b) {
-    Real ok, dk, oa, da, ob, db;
-    if (type == RTR_NODE_XY_RECT) {
-        ok = o.z, dk = d.z, oa = o.x, da = d.x, ob = o.y, db = d.y;
-    } else if (type == RTR_NODE_XZ_RECT) {
-        ok = o.y, dk = d.y, oa = o.x, da = d.x, ob = o.z, db = d.z;
-    } else {
-        ok = o.x, dk = d.x, oa = o.y, da = d.y, ob = o.z, db = d.z;
-    }
+RT_DEV bool rect_hit_axes(const rtr_node& n, Real ok, Real dk, Real oa, Real da, Real ob, Real db, Real tmin, Real tmax,
+                          Real& t, Real& a, Real& b) {
     /* same tests as aarect.h:80-88 (a NaN fails none of the rejects there, nor here), evaluated
      * without early exits: lanes of a wave diverge on them anyway */
     t = (n.f[4] - ok) / dk;
@@ -338,6 +331,24 @@ RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real 
     b = ob + t * db;
     const bool out = (t < tmin) | (t > tmax) | (a < n.f[0]) | (a > n.f[1]) | (b < n.f[2]) | (b > n.f[3]);
     return !out;
+}
+RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real tmax, Real& t, Real& a, Real& b) {
+    /* one copy of the test per orientation: `type` is wave-uniform wherever the record came through
+     * scalar loads, so this is a scalar branch, and no copy shuffles ray components through moves */
+    /* (the empty asm statements differ, which keeps the optimiser from folding the copies back into one
+     * body behind a chain of selects) */
+    bool hit;
+    if (type == RTR_NODE_XY_RECT) {
+        hit = rect_hit_axes(n, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t, a, b);
+        asm volatile("; xy_rect" : "+v"(t));
+    } else if (type == RTR_NODE_XZ_RECT) {
+        hit = rect_hit_axes(n, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t, a, b);
+        asm volatile("; xz_rect" : "+v"(t));
+    } else {
+        hit = rect_hit_axes(n, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t, a, b);
+        asm volatile("; yz_rect" : "+v"(t));
+    }
+    return hit;
 }
 RT_DEV void rect_fill(const rtr_node& n, int type, V3 o, V3 d, Real t, Real a, Real b, bool needs_uv, Hit& rec) {
     if (needs_uv) {
