@@ -24,7 +24,10 @@ typedef struct rtr_scene_info {
     int32_t fast_instances, fast_refs, fast_stack_words;
     int32_t compiled_subtrees; /* media scenes: media-free subtrees compiled inside the reference-order walk */
     int32_t program_steps;     /* media scenes: steps of the ray-cast program (0: media not directly under the root list) */
-    int32_t reserved[2];
+    int32_t inverted_boxes;    /* spheres with a negative radius (hollow glass): sphere::bounding_box (sphere.h:62-66)
+                                  then has min > max, the bvh_node boxes built from it do not enclose the sphere,
+                                  and which rays still reach it depends on the reference's visiting order */
+    int32_t reserved[1];
 } rtr_scene_info;
 
 /* Host-only: the checks rtr_upload_scene() runs before touching the GPU.  Returns RTR_OK,

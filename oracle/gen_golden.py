@@ -136,6 +136,9 @@ def write_pbr_textures(td):
         write_png(os.path.join(td, rel), 24 + 2 * (k % 3), 20 + k, k, ctype, depth)
 
 
+# scene ids without a dedicated fixture set above
+ALL_OTHER_SCENES = [2, 5, 6, 10, 11, 12, 13, 14, 16, 20, 25, 27, 28, 30, 31, 32, 33, 34, 36, 37, 38, 39, 40, 41, 42]
+
 HDR_ASSETS = {24: ("brown_photostudio_02_4k.hdr", 32, 16, {(20, 4), (21, 4), (20, 5)}),
               26: ("rnl_probe.hdr", 16, 16, {(11, 5), (4, 9)})}
 
@@ -287,6 +290,27 @@ def main():
         name = "img_scene35_i4_64_spp16.f64"
         cmd, info = run("render", 35, 4, 64, 16, 1, SCENE_SEED, os.path.join(GOLD, name), 8, cwd=td)
         note(name, cmd, info, scene=35, integrator=4, width=64, height=info["height"], spp=16, seed=1)
+
+    # breadth: every other scene id of the reference's select_scene (scenes.cpp:1523-2096), flattened and
+    # rendered small by the reference itself (no assets present: missing-file fallbacks), so that
+    # oracle and device are compared with the reference on each material / light / geometry mix
+    for sid in ALL_OTHER_SCENES:
+        name = "scene%02d.rtrs" % sid
+        path = os.path.join(GOLD, name)
+        cmd, info = run("dump-scene", sid, SCENE_SEED, path)
+        raw_sha = sha(path)
+        if os.path.getsize(path) > 60_000:
+            with open(path, "rb") as f:
+                data = f.read()
+            with open(path + ".gz", "wb") as f:
+                f.write(gzip.compress(data, 9, mtime=0))
+            os.remove(path)
+            note(name + ".gz", cmd, info, raw_sha256=raw_sha)
+        else:
+            note(name, cmd, info, raw_sha256=raw_sha)
+        name = "img_scene%02d_i4_32_spp4.f64" % sid
+        cmd, info = run("render", sid, 4, 32, 4, 1, SCENE_SEED, os.path.join(GOLD, name), 8)
+        note(name, cmd, info, scene=sid, integrator=4, width=32, height=info["height"], spp=4, seed=1)
 
     # one mid-size image of the headline config's scene
     name = "img_scene21_i4_128_spp32.f64"

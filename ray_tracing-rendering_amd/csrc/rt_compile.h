@@ -392,7 +392,12 @@ struct SubtreeFacts {
             child(n.a);
             m = 1;
             break;
-        default: p = 1;
+        default:
+            p = 1;
+            /* a sphere with a negative radius has an inverted bounding box in the reference
+             * (sphere.h:62-66): the bvh_node boxes above it do not enclose it, so whether a ray reaches
+             * it is decided by those boxes and the running t_max -- keep the reference's walk there */
+            m = (n.type == RTR_NODE_SPHERE && n.f[3] < 0) || (n.type == RTR_NODE_MOVING_SPHERE && n.f[8] < 0);
         }
         prims[ix] = p;
         media[ix] = m;
@@ -406,6 +411,7 @@ struct SubtreeFacts {
  *  - media: ok = false (the reference-order walk stays in charge), but every media-free subtree
  *    with at least kMinCompiled primitives met on the way down from the root is compiled and its
  *    node replaced by RT_NODE_COMPILED in the device copy of the node array. */
+/* `has_media`: the graph holds a constant_medium or an inverted box (order-sensitive parts) */
 inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) {
     CompiledScene cs;
     cs.dev_nodes.assign(scene->nodes, scene->nodes + scene->n_nodes);

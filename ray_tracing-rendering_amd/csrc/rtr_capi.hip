@@ -269,6 +269,12 @@ struct Validator {
         if (info) {
             info->stack_words = std::max(1, need[s->root]);
             info->has_media = media[s->root];
+            int inverted = 0;
+            for (int k = 0; k < s->n_nodes; ++k)
+                if (state[k] == 2 && ((s->nodes[k].type == RTR_NODE_SPHERE && s->nodes[k].f[3] < 0) ||
+                                      (s->nodes[k].type == RTR_NODE_MOVING_SPHERE && s->nodes[k].f[8] < 0)))
+                    ++inverted;
+            info->inverted_boxes = inverted;
             info->graph_depth = depth[s->root];
             int uv = 0;
             for (int k = 0; k < s->n_textures; ++k)
@@ -317,7 +323,7 @@ std::vector<int> owned_tiles(const rtr_render_params& p, int& tiles_x, int& tile
 /* which traversal a call uses: the compiled scene unless it does not exist or the caller asks
  * for the reference's visiting order */
 int pick_trav(const rtr_context* c, int flags) {
-    if (c->info.has_media)
+    if (c->info.has_media || c->info.inverted_boxes)
         return c->info.program_steps > 0 && !c->force_exact && !(flags & RTR_FLAG_REFERENCE_ORDER) ? RT_TRAV_PROGRAM
                                                                                                      : RT_TRAV_MEDIA;
     if (!c->info.fast_ok || c->uv_order_dependent || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER))
@@ -453,7 +459,7 @@ int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* 
         std::snprintf(msg, msg_cap, "%s", v.msg.c_str());
     }
     if (rc == RTR_OK && info) {
-        CompiledScene cs = compile_scene(scene, info->has_media != 0);
+        CompiledScene cs = compile_scene(scene, info->has_media != 0 || info->inverted_boxes != 0);
         info->fast_ok = cs.ok;
         info->fast_instances = (int32_t)cs.inst.size();
         info->fast_refs = (int32_t)cs.ref.size();
@@ -540,7 +546,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
-    CompiledScene cs = compile_scene(s, info.has_media != 0);
+    CompiledScene cs = compile_scene(s, info.has_media != 0 || info.inverted_boxes != 0);
     if ((rc = upload(c, c->b_nodes, cs.dev_nodes.data(), sizeof(rtr_node) * cs.dev_nodes.size()))) return rc;
     if ((rc = upload(c, c->b_kids, s->list_children, sizeof(int32_t) * s->n_list_children))) return rc;
     if ((rc = upload(c, c->b_mats, s->materials, sizeof(rtr_material) * s->n_materials))) return rc;

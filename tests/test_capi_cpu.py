@@ -58,6 +58,17 @@ def test_validate_golden_scenes(sid, words, media):
         assert info["program_steps"] == 5
 
 
+@pytest.mark.parametrize("sid,inverted", [(30, 1), (33, 1), (34, 1), (39, 1), (40, 1), (23, 0), (1, 0)])
+def test_hollow_spheres_keep_the_reference_walk(sid, inverted):
+    """A sphere with a negative radius (hollow glass) has min > max in sphere::bounding_box, so the
+    reference's bvh_node boxes above it do not enclose it and some rays that would hit it are culled:
+    the order-free compiled traversal would see MORE than the reference does (found by rendering
+    every scene id against the reference).  Such scenes keep the reference-order walk."""
+    info = rtr.native.validate_scene(G.scene(sid))
+    assert info["inverted_boxes"] == inverted
+    assert info["fast_ok"] == (inverted == 0)
+
+
 def _mutated(sid, fn):
     sc = rtr.Scene.from_bytes(G.scene(sid).to_bytes())
     fn(sc)

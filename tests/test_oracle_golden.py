@@ -168,6 +168,22 @@ def test_images(name):
     assert G.rel_l2(out, img) == 0.0
 
 
+ALL_OTHER_SCENES = [2, 5, 6, 10, 11, 12, 13, 14, 16, 20, 25, 27, 28, 30, 31, 32, 33, 34, 36, 37, 38, 39, 40, 41, 42]
+
+
+@pytest.mark.parametrize("sid", ALL_OTHER_SCENES)
+def test_every_other_reference_scene(sid):
+    """Breadth: each remaining scene id of select_scene (scenes.cpp:1523-2096), flattened and rendered
+    small by the reference (MIS integrator): the oracle reproduces the image bit for bit."""
+    img, info = G.image("img_scene%02d_i4_32_spp4.f64" % sid)
+    sc = G.scene(sid)
+    p = A.make_params(info["width"], info["height"], info["spp"], integrator=4, seed=info["seed"])
+    out, stats = G.oracle_render(sc, p, threads=4)
+    assert stats["closest_segments"] + stats["shadow_segments"] == \
+        info["info"]["closest_segments"] + info["info"]["shadow_segments"]
+    assert np.array_equal(_bits(out), _bits(img))
+
+
 def test_image_texture_fixture_really_has_texels():
     """scene 4 was flattened with a loaded image (not the cyan missing-file fallback)."""
     sc = G.scene(4)
