@@ -645,15 +645,33 @@ RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, Real time, Real tmin, R
     sphere_geom(n, type, time, center, radius);
     return sphere_hit_t(center, radius, o, d, tmin, tmax, t);
 }
-RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
+/* Exact ties in t.  Every hit() of the reference accepts t == t_max, so of two surfaces at exactly the
+ * same t the one its walk visits LATER wins (two coplanar rects with different materials).  Upload marks
+ * the references that can tie with another one of their instance (same plane and overlapping extent,
+ * or the same sphere twice) with RT_TIE_FLAG and stores their visiting position next to it; only those
+ * pay for the comparison: a tie is accepted only from a primitive visited later than the current
+ * holder.  Not reproduced: ties across instances, and ties where the reference's own choice hangs on
+ * 1-ulp noise of an UNPADDED box test (faces of `box` objects that touch: the later one is only
+ * visited if aabb::hit of its box, entered at exactly that t, survives `t_max <= t_min`). */
+#define RT_TIE_FLAG (1 << 30)
+template <bool TIES = true>
+RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t, int& order) {
     const rtr_node n = ld_const(sc.fprim, ref);
-    return fast_prim_hit(n, o, d, time, tmin, tmax, t);
+    if (!fast_prim_hit(n, o, d, time, tmin, tmax, t)) return false;
+    const int tag = n.reserved;
+    if (TIES && (tag & RT_TIE_FLAG)) {
+        const int visit = tag & ~RT_TIE_FLAG;
+        if (t == tmax && visit < order) return false;
+        order = visit;
+    }
+    return true;
 }
 
 /* Closest hit (ANY = false) or first hit found (ANY = true: shadow rays only need existence).
  * Returns the reference and instance of the hit; `tmax` returns its t.  TREES = false: the caller
- * knows that no instance of the scene has a box tree (RT_TRAV_FLAT), which keeps that code and
- * its registers out of the kernels of small scenes (the Cornell box: 122 VGPRs, no spills). */
+ * knows that no instance of the scene has a box tree and no reference is tie-capable (RT_TRAV_FLAT),
+ * which keeps that code and its registers out of the kernels of small scenes (the Cornell box:
+ * 118 VGPRs, no spills). */
 template <bool ANY, bool TREES>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
                                            Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
@@ -665,6 +683,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
     if (use_boxes) inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     hit_ref = -1;
     hit_inst = -1;
+    int order = -1;
     for (int ii = inst_first; ii < inst_first + n_inst; ++ii) {
         const FInst I = ld_const(sc.finst, ii);
         V3 lo = o, ld = d;
@@ -683,7 +702,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
             const int r0 = I.ref_first, r1 = r0 + I.n_ref;
             for (int r = r0; r < r1; ++r) {
                 Real t;
-                if (fast_ref_hit(sc, r, lo, ld, time, tmin, tmax, t)) {
+                if (fast_ref_hit<TREES>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
                     tmax = t;
                     hit_ref = r;
                     hit_inst = ii;
@@ -722,7 +741,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                 const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
                 for (int r = r0; r < r1; ++r) {
                     Real t;
-                    if (fast_ref_hit(sc, r, lo, ld, time, tmin, tmax, t)) {
+                    if (fast_ref_hit<TREES>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
                         tmax = t;
                         tmax_f = float_above(t);
                         hit_ref = r;
@@ -790,7 +809,7 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
 #define RT_TRAV_MEDIA 1
 #define RT_TRAV_FAST 2
 #define RT_TRAV_PROGRAM 3 /* scenes with media: the step program (struct FStep) */
-#define RT_TRAV_FLAT 4    /* compiled scene none of whose instances has a box tree */
+#define RT_TRAV_FLAT 4    /* compiled scene without box trees and without tie-capable references */
 
 /* Run the ray-cast program over [tmin, tmax].  Returns whether anything was hit; then `tmax` is
  * the hit's t and either `med` >= 0 (the step of the medium that scattered the ray) or

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -44,7 +45,7 @@ struct rtr_context {
     bool force_exact = false;
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
     bool quad_lights_only = false;
-    bool flat_scene = false; /* compiled scene without box trees */
+    bool flat_scene = false; /* compiled scene without box trees and without tie-capable references */
     /* a moving_sphere (its hit() writes no u,v: the record keeps those of an earlier, farther hit of the
      * reference's walk) carries a material that reads (u,v): only the reference-order walk reproduces that */
     bool uv_order_dependent = false;
@@ -568,16 +569,44 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     if ((rc = upload(c, c->b_fsub, cs.subs.data(), sizeof(FSub) * cs.subs.size()))) return rc;
     if ((rc = upload(c, c->b_fstep, cs.steps.data(), sizeof(FStep) * cs.steps.size()))) return rc;
     info.program_steps = (int32_t)cs.steps.size();
+    bool any_tie = false;
     {
         std::vector<rtr_node> prims(cs.ref.size());
         for (size_t k = 0; k < cs.ref.size(); ++k) {
             prims[k] = s->nodes[cs.ref[k].node]; /* original records */
             prims[k].reserved = cs.ref[k].pad;      /* visiting order of the reference's walk */
         }
+        /* references that can tie exactly in t with another one of their instance (see RT_TIE_FLAG) */
+        for (const FInst& I : cs.inst) {
+            std::map<std::vector<uint64_t>, std::vector<int>> groups; /* same plane / same sphere */
+            auto bits = [](double v) {
+                uint64_t u;
+                std::memcpy(&u, &v, 8);
+                return u;
+            };
+            for (int r = I.ref_first; r < I.ref_first + I.n_ref; ++r) {
+                const rtr_node& n = prims[r];
+                if (n.type >= RTR_NODE_XY_RECT)
+                    groups[{(uint64_t)n.type, bits(n.f[4])}].push_back(r);
+                else if (n.type == RTR_NODE_SPHERE)
+                    groups[{(uint64_t)n.type, bits(n.f[0]), bits(n.f[1]), bits(n.f[2]), bits(std::fabs(n.f[3]))}].push_back(r);
+            }
+            for (const auto& g : groups) {
+                const std::vector<int>& v = g.second;
+                for (size_t x = 0; x < v.size(); ++x)
+                    for (size_t y = x + 1; y < v.size(); ++y) {
+                        rtr_node &p = prims[v[x]], &q = prims[v[y]];
+                        const bool overlap = p.type == RTR_NODE_SPHERE ||
+                                             (std::max(p.f[0], q.f[0]) <= std::min(p.f[1], q.f[1]) &&
+                                              std::max(p.f[2], q.f[2]) <= std::min(p.f[3], q.f[3]));
+                        if (overlap) p.reserved |= RT_TIE_FLAG, q.reserved |= RT_TIE_FLAG, any_tie = true;
+                    }
+            }
+        }
         if ((rc = upload(c, c->b_fprim, prims.data(), sizeof(rtr_node) * prims.size()))) return rc;
     }
     c->fast_stack_words = cs.stack_words;
-    c->flat_scene = cs.ok && cs.bvh.empty();
+    c->flat_scene = cs.ok && cs.bvh.empty() && !any_tie;
     c->walk_extra_words = cs.n_compiled_subtrees ? cs.stack_words : 0;
     DScene& d = c->ds;
     d.finst = static_cast<const FInst*>(c->b_finst.p);

@@ -385,6 +385,60 @@ def test_every_other_reference_scene(ctx, sid):
         assert G.rel_l2(out, img) <= 5e-2
 
 
+EVERY_SCENE = sorted(set(ALL_OTHER_SCENES) | {1, 4, 7, 8, 9, 15, 17, 18, 19, 21, 22, 23, 24, 26, 35})
+
+
+@pytest.mark.parametrize("sid", EVERY_SCENE)
+def test_default_traversal_equals_reference_order_on_every_scene(ctx, sid):
+    """Whatever upload picks for a scene (flat / compiled scene / step program / walk with compiled
+    subtrees) must give the bits of the reference-order walk: 3072 random rays through the scene
+    (hit flag, t, p, n, material, front_face, RNG state) and a small render per pipeline."""
+    sc = _upload(ctx, sid)
+    cam = np.array(sc.camera["origin"], dtype=np.float64).reshape(3)
+    corner = np.array(sc.camera["lower_left_corner"], dtype=np.float64).reshape(3)
+    hor = np.array(sc.camera["horizontal"], dtype=np.float64).reshape(3)
+    ver = np.array(sc.camera["vertical"], dtype=np.float64).reshape(3)
+    rng = np.random.default_rng(1000 + sid)
+    n = 3072
+
+    def both(rays):
+        ctx.reference_order(False)
+        a = ctx.test_records("hits", rays)
+        ctx.reference_order(True)
+        b = ctx.test_records("hits", rays)
+        ctx.reference_order(False)
+        assert np.array_equal(a["hit"], b["hit"]) and np.array_equal(a["rng_out"], b["rng_out"])
+        h = b["hit"] == 1
+        for f in ("front_face", "material"):
+            assert np.array_equal(a[f][h], b[f][h]), f
+        for f in ("t", "p", "n"):
+            assert np.array_equal(_bits(a[f][h]), _bits(b[f][h])), f
+        return b
+
+    # rays a render can produce: camera rays, then rays leaving the surfaces those hit (the artificial
+    # alternative, origins inside solids or below floors, meets exact ties the reference itself
+    # resolves by 1-ulp noise of unpadded box tests -- see RT_TIE_FLAG in rt_device.h)
+    rays = np.zeros(n, dtype=A.HIT_DTYPE)
+    uv = rng.random((n, 2))
+    rays["o"] = cam
+    rays["d"] = corner + uv[:, :1] * hor + uv[:, 1:] * ver - cam
+    rays["time"] = rng.random(n)
+    rays["t_min"], rays["t_max"], rays["rng_in"] = 0.001, np.inf, 12345
+    first = both(rays)
+    assert 0.05 < first["hit"].mean(), "the camera rays miss the scene"
+    h = first["hit"] == 1
+    second = rays[h].copy()
+    d = rng.normal(0.0, 1.0, (len(second), 3))
+    d = np.where((np.sum(d * first["n"][h], axis=1) < 0)[:, None], -d, d)
+    second["o"], second["d"] = first["p"][h], d
+    both(second)
+    integ = 4 if len(sc.lights) else 1
+    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
+        x = ctx.render(A.make_params(48, 32, 2, integrator=integ, seed=77, pipeline=pipe))
+        y = ctx.render(A.make_params(48, 32, 2, integrator=integ, seed=77, pipeline=pipe, flags=A.FLAG_REFERENCE_ORDER))
+        assert np.array_equal(_bits(x), _bits(y)), pipe
+
+
 def test_image_texture(ctx):
     """image_texture with real texels (scene 4 + synthetic picture): (u,v) from
     acos/atan2 on the sphere, nearest-texel fetch.  Runs the compiled traversal, which rebuilds
