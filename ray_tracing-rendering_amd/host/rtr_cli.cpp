@@ -4,14 +4,14 @@
  * overrides the BASELINE configurations need (--width --spp --seed --out).  It is the
  * reference-side usage of the host layer: select_scene -> camera -> Renderer::render -> file.
  *
- *   rtr_cli <scene 7|9|21|22|23> <integrator 0..4> [--width W] [--spp N] [--seed S] [--out img.ppm]
+ *   rtr_cli <scene 7|9|21|22|23> <integrator 0..4> [--width W] [--spp N] [--seed S] [--bands N] [--out img.ppm]
  */
 #include "rtr_renderer.h"
 
 #include <cstring>
 
 int main(int argc, char** argv) {
-    int scene_id = 21, integrator_id = 4, width = 0, spp = 0;
+    int scene_id = 21, integrator_id = 4, width = 0, spp = 0, bands = 0;
     unsigned seed = 1;
     std::string out;
     int pos = 0;
@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[k], "--spp") && k + 1 < argc) spp = std::atoi(argv[++k]);
         else if (!std::strcmp(argv[k], "--seed") && k + 1 < argc) seed = (unsigned)std::strtoul(argv[++k], nullptr, 0);
         else if (!std::strcmp(argv[k], "--out") && k + 1 < argc) out = argv[++k];
+        else if (!std::strcmp(argv[k], "--bands") && k + 1 < argc) bands = std::atoi(argv[++k]);
         else if (pos == 0) scene_id = std::atoi(argv[k]), ++pos;
         else if (pos == 1) integrator_id = std::atoi(argv[k]), ++pos;
     }
@@ -48,6 +49,7 @@ int main(int argc, char** argv) {
     }
     renderer.set_max_depth(50); /* main.cpp:102 */
     renderer.set_seed(seed);
+    renderer.set_progress_bands(bands);
     renderer.render(config.world, cam, config.background, buffer, config.lights);
     if (renderer.last_status() != RTR_OK) return 1;
     std::cout << "Msamples/s: " << (double)W * H * config.samples_per_pixel / renderer.last_seconds() * 1e-6

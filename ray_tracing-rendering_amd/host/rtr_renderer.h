@@ -135,6 +135,13 @@ class Renderer {
         if (m_integrator) m_integrator->set_max_depth(depth);
     }
     void set_seed(uint32_t seed) { m_seed = seed; } /* the reference has no seed control */
+    /* The reference's workers store pixels as they finish tiles and main.cpp:124 polls
+     * RenderBuffer::get_data() meanwhile.  Here the image is rendered in `n` horizontal bands of whole
+     * tile rows, top band first like the reference's tile order (renderer.h:61-62), and every band is
+     * stored as soon as it arrives; cancel() takes effect between bands, too.  0 = pick by image
+     * height (one band per 256 rows).  Per-sample seeds depend on (pixel, sample) only, so the
+     * result does not depend on n. */
+    void set_progress_bands(int n) { m_bands = n; }
     void cancel() {
         m_is_rendering = false;
         if (m_ctx) rtr_cancel(m_ctx);
@@ -179,15 +186,27 @@ class Renderer {
         p.pipeline = RTR_PIPELINE_AUTO;
         p.tile_first = 0, p.tile_stride = 1;
         p.spp_chunks = 0;
-        std::vector<double> lin((size_t)W * H * 3);
-        rc = rtr_render_host(m_ctx, &p, lin.data(), W);
-        if (rc) return m_error = rtr_last_error(m_ctx), rc;
-        for (int j = 0; j < H; ++j)
-            for (int i = 0; i < W; ++i) { /* write_color_to_buffer, renderer.h:126-140 */
-                const double* px = &lin[((size_t)j * W + i) * 3];
-                buf.set_pixel(i, j, color(clamp(sqrt(px[0]), 0.0, 1.0), clamp(sqrt(px[1]), 0.0, 1.0),
-                                          clamp(sqrt(px[2]), 0.0, 1.0)));
-            }
+        int bands = m_bands > 0 ? m_bands : (H + 255) / 256;
+        const int tile_rows = (H + 15) / 16;
+        bands = std::max(1, std::min(bands, tile_rows));
+        std::vector<double> lin;
+        for (int b = 0; b < bands; ++b) { /* row 0 of the buffer is the bottom row; the top band goes first */
+            const int r1 = tile_rows - (int)((long long)b * tile_rows / bands);
+            const int r0 = tile_rows - (int)((long long)(b + 1) * tile_rows / bands);
+            const int y0 = r0 * 16, y1 = std::min(H, r1 * 16);
+            if (y0 >= y1) continue;
+            if (!m_is_rendering) return m_error = "render cancelled", RTR_ERR_CANCELLED;
+            p.y0 = y0, p.y1 = y1;
+            lin.assign((size_t)W * (y1 - y0) * 3, 0.0);
+            rc = rtr_render_host(m_ctx, &p, lin.data(), W);
+            if (rc) return m_error = rtr_last_error(m_ctx), rc;
+            for (int j = y0; j < y1; ++j)
+                for (int i = 0; i < W; ++i) { /* write_color_to_buffer, renderer.h:126-140 */
+                    const double* px = &lin[((size_t)(j - y0) * W + i) * 3];
+                    buf.set_pixel(i, j, color(clamp(sqrt(px[0]), 0.0, 1.0), clamp(sqrt(px[1]), 0.0, 1.0),
+                                              clamp(sqrt(px[2]), 0.0, 1.0)));
+                }
+        }
         return RTR_OK;
     }
 
@@ -197,6 +216,7 @@ class Renderer {
     rtr_context* m_ctx = nullptr;
     int m_status = RTR_OK;
     uint32_t m_seed = 1;
+    int m_bands = 0;
     double m_seconds = 0;
     std::string m_error;
 };

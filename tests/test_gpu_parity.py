@@ -530,6 +530,13 @@ def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
     rb = rtr.RenderBuffer(64, 64)
     rb.store_linear(ctx.render(A.make_params(64, 64, 4, seed=3, spp_chunks=0)))
     assert np.array_equal(got, rb.to_rgb8())
+    # progressive bands (what keeps the reference's polling UI fed): same pixels for any band count
+    for bands in (1, 3):
+        out_b = str(tmp_path / ("cli_b%d.ppm" % bands))
+        r = subprocess.run([cli, "21", "4", "--width", "64", "--spp", "4", "--seed", "3", "--bands", str(bands), "--out", out_b],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        assert open(out_b, "rb").read() == raw
 
 
 def test_error_behaviour(ctx, rtr):
