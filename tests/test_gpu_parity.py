@@ -439,6 +439,25 @@ def test_default_traversal_equals_reference_order_on_every_scene(ctx, sid):
         assert np.array_equal(_bits(x), _bits(y)), pipe
 
 
+@pytest.mark.parametrize("sid", EVERY_SCENE)
+def test_other_integrators_on_every_scene(ctx, sid):
+    """Breadth for integrators 0-3 (plain path, roulette path, BSDF-only, NEE): every scene, small
+    render, device vs the oracle (which the golden vectors pin to the reference for all five
+    integrators).  Same per-pixel bar as test_every_other_reference_scene."""
+    sc = _upload(ctx, sid)
+    W, H = 32, 20
+    for integ in (0, 1, 2, 3):
+        p = A.make_params(W, H, 3, integrator=integ, seed=5, max_depth=12 if integ == 0 else 50)
+        ora, ost = G.oracle_render(sc, p, threads=0)
+        pipes = (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT) if integ == 1 else (A.PIPELINE_MEGAKERNEL,)
+        for pipe in pipes:
+            q = A.make_params(W, H, 3, integrator=integ, seed=5, max_depth=12 if integ == 0 else 50, pipeline=pipe)
+            out = ctx.render(q)
+            close = np.all(_close(out, ora, 1e-9) | (np.abs(out - ora) <= 1e-12), axis=-1)
+            assert close.mean() >= 0.985, (integ, pipe, close.mean())
+            assert G.rel_l2(out, ora) <= 5e-2 or np.abs(out - ora).max() <= 1e-12, (integ, pipe)
+
+
 def test_image_texture(ctx):
     """image_texture with real texels (scene 4 + synthetic picture): (u,v) from
     acos/atan2 on the sphere, nearest-texel fetch.  Runs the compiled traversal, which rebuilds
