@@ -53,6 +53,18 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
 #define RTR_PROGRAM_WAVES 3 /* media scenes are traversal-latency bound: a third wave pays for the spills it causes */
 #endif
 
+/* Waves per SIMD the register allocator must leave room for, per kernel variant (measured: scene 23
+ * 4.36 -> 5.12, scene 1 1.36 -> 1.63 Gsamples/s at 3 instead of 2; the variants with the full light
+ * set or the reference-order walk lose 10-30 % there to spills) */
+constexpr int mega_waves(int integ, int trav, int ms) {
+    if (ms == RT_MS_LEAN) return RTR_MEGA_WAVES;
+    if (trav == RT_TRAV_PROGRAM) return RTR_PROGRAM_WAVES;
+    if (trav == RT_TRAV_MEDIA || trav == RT_TRAV_EXACT) return 2;
+    if (ms == RT_MS_QUADLIT) return 3;
+    if (integ == RTR_INTEGRATOR_RR || integ == RTR_INTEGRATOR_PATH) return 3;
+    return 2;
+}
+
 /* Per-lane path state that the ray casts do not touch lives in LDS between shading steps
  * ("parked"), so it does not occupy VGPRs across the traversal loops: throughput, radiance of
  * the sample, pixel sum, previous BSDF pdf and the pending light contribution.  Word k of lane l
@@ -70,7 +82,7 @@ struct Park {
 enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_CONTRIB = 9, PK_PDF = 12, PK_SWI = 13, PK_STMAX = 16, PK_NCLOSEST = 17, PK_NSHADOW = 18 };
 
 template <int INTEG, int TRAV, int MS>
-__global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? RTR_MEGA_WAVES : (TRAV == RT_TRAV_PROGRAM ? RTR_PROGRAM_WAVES : 2))
+__global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
     k_mega(const DScene* __restrict__ scp, const RenderK P, const int stack_words) {
     extern __shared__ int lds_stack[];
     const DScene& sc = *scp;
