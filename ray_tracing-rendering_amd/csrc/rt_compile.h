@@ -1,7 +1,11 @@
 /*
- * rt_compile.h -- host side: lower a validated hittable graph (no constant_medium) to the
- * compiled scene of rt_device.h (instances / references / wrapper epilogue lists / box trees).
- * See the comment above `struct FInst` for why this is result-preserving.
+ * rt_compile.h -- host side: lower a validated hittable graph to the compiled scene of rt_device.h
+ * (instances / references / wrapper epilogue lists / SAH box trees with single-precision boxes).
+ *   - no order-sensitive part: sub-scene 0 = the whole graph (RT_TRAV_FAST / RT_TRAV_FLAT);
+ *   - constant_media under bvh_nodes / lists: the step program (FStep, RT_TRAV_PROGRAM);
+ *   - anything else that is order-sensitive (a medium under a transform, a sphere with a negative
+ *     radius): the reference-order walk with every large media-free subtree compiled (RT_NODE_COMPILED).
+ * See the comments above `struct FInst`, `struct FStep` and `struct FBvh` for why each is result-preserving.
  */
 #pragma once
 

@@ -7,8 +7,8 @@
  * Numerics contract ("exact" build, -ffp-contract=off): every expression keeps the
  * reference's operation order in IEEE binary64 (division and sqrt correctly rounded), so
  * results are bit-identical to the reference wherever no libm transcendental is involved
- * (all of the Cornell scenes); sin/cos/pow/log/acos/atan2 come from OCML and may differ
- * from glibc in the last ulp (scenes 23, 9, 22).  RNG draws are sequenced in the order
+ * (all of the Cornell scenes); sin/cos/log/acos/atan2 come from OCML and may differ from
+ * glibc in the last ulp (scenes 23, 9, 22); pow(x, 5) is a correctly rounded x^5 (pow5).  RNG draws are sequenced in the order
  * g++ evaluates the reference's argument lists.
  *
  * Citations are reference paths relative to /root/reference/src.
@@ -164,7 +164,7 @@ struct DScene {
     int32_t n_nodes;
     int32_t n_lights;
     int32_t needs_uv; /* some texture reads (u,v): image textures */
-    /* compiled scene for the order-free fast path (scenes without media), see trace_fast() */
+    /* compiled scene for the order-free traversal (trace_fast); scenes with media use it per step (FStep) */
     const struct FInst* finst;
     const struct FXf* fxf;
     const struct FRef* fref;
@@ -187,7 +187,7 @@ struct DScene {
  *               world-space box of the set; the ray is moved into the instance's frame once;
  *   reference = one primitive of an instance + the wrappers (translate, rotate_y, flip_face) it
  *               sits under, innermost first, whose hit() epilogues are replayed on the hit record;
- *   BVH       = median-split box tree over an instance's references when there are many.
+ *   BVH       = SAH box tree (struct FBvh) over an instance's references when there are many.
  * Every primitive test and every epilogue uses the same arithmetic as the reference's hit()
  * functions, so the hit record is bit-identical to the reference-order traversal.
  */
