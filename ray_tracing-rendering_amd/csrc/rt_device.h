@@ -457,7 +457,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
     while (sp > sp0) {
         const int e = st.get(--sp);
         if (e < 0) { /* leaving wrapper node -(e+1) */
-            const rtr_node& n = sc.nodes[-(e + 1)];
+            const rtr_node n = ld_const(sc.nodes, -(e + 1));
             const bool inside = st.get(--sp) != hits;
             const int type = n.type;
             if (FULL && inside) wrapper_epilogue(n, d, rec);
@@ -472,7 +472,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
             }
             continue;
         }
-        const rtr_node& n = sc.nodes[e];
+        const rtr_node n = ld_const(sc.nodes, e);
         const int type = n.type;
         if (type == RTR_NODE_BVH) {
             if (aabb_hit(n.f, o, inv, tmin, tmax)) {
@@ -496,7 +496,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
                 if (FULL) sphere_fill(n, type, center, radius, o, d, t, sc.needs_uv != 0, rec);
             }
         } else if (type == RTR_NODE_LIST) {
-            for (int k = n.b - 1; k >= 0; --k) st.put(sp++, sc.list_children[n.a + k]);
+            for (int k = n.b - 1; k >= 0; --k) st.put(sp++, as_const(sc.list_children)[n.a + k]);
         } else if (type == RTR_NODE_TRANSLATE) { /* geometry/hittable.h:51-56 */
             st.putd(sp, o.x), st.putd(sp + 2, o.y), st.putd(sp + 4, o.z);
             sp += 6;
@@ -927,7 +927,11 @@ __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real t
     return traverse<false, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, 0.0, 0.001, tmax, dummy, rng, st, 0);
 }
 /* ---- materials/perlin.h:21-111 -------------------------------------------------------------- */
-RT_DEV Real perlin_noise(const rtr_perlin& pn, V3 p) {
+RT_DEV Real perlin_noise(const rtr_perlin* pnp, V3 p) {
+    const RT_CONST_AS int32_t* perm_x = as_const(&pnp->perm_x[0]);
+    const RT_CONST_AS int32_t* perm_y = as_const(&pnp->perm_y[0]);
+    const RT_CONST_AS int32_t* perm_z = as_const(&pnp->perm_z[0]);
+    const RT_CONST_AS double* ranvec = as_const(&pnp->ranvec[0][0]);
     const Real fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
     const Real u = p.x - fx, v = p.y - fy, w = p.z - fz;
     const int i = (int)fx, j = (int)fy, k = (int)fz;
@@ -941,15 +945,15 @@ RT_DEV Real perlin_noise(const rtr_perlin& pn, V3 p) {
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const int ix = pn.perm_x[(i + a) & 255] ^ pn.perm_y[(j + b) & 255] ^ pn.perm_z[(k + c) & 255];
-                V3 cv = ld3(pn.ranvec[ix]);
+                const int ix = perm_x[(i + a) & 255] ^ perm_y[(j + b) & 255] ^ perm_z[(k + c) & 255];
+                V3 cv = mk(ranvec[3 * ix], ranvec[3 * ix + 1], ranvec[3 * ix + 2]);
                 V3 weight_v = mk(u - a, v - b, w - c);
                 accum += (a * uu + (1 - a) * (1 - uu)) * (b * vv + (1 - b) * (1 - vv)) *
                          (c * ww + (1 - c) * (1 - ww)) * dot(cv, weight_v);
             }
     return accum;
 }
-RT_DEV Real perlin_turb(const rtr_perlin& pn, V3 p) { /* perlin.h:41-54 */
+RT_DEV Real perlin_turb(const rtr_perlin* pn, V3 p) { /* perlin.h:41-54 */
     Real accum = 0.0;
     V3 temp_p = p;
     Real weight = 1.0;
@@ -966,7 +970,7 @@ RT_DEV Real perlin_turb(const rtr_perlin& pn, V3 p) { /* perlin.h:41-54 */
 __device__ __forceinline__ V3 tex_value_slow(const DScene& sc, int ix, Real u, Real v, V3 p) {
     /* checker textures nest (texture.h:60-66); unrolled to a bounded loop instead of recursion */
     for (int guard = 0; guard < 8; ++guard) {
-        const rtr_texture& t = sc.textures[ix];
+        const rtr_texture t = ld_const(sc.textures, ix);
         const int type = t.type;
         if (type == RTR_TEX_SOLID) return ld3(t.f);
         if (type == RTR_TEX_CHECKER) { /* texture.h:68-75 */
@@ -975,12 +979,12 @@ __device__ __forceinline__ V3 tex_value_slow(const DScene& sc, int ix, Real u, R
             continue;
         }
         if (type == RTR_TEX_NOISE) { /* texture.h:155-158 */
-            Real x = 1 + sin(t.f[0] * p.z + 10 * perlin_turb(sc.perlin[t.a], p));
+            Real x = 1 + sin(t.f[0] * p.z + 10 * perlin_turb(sc.perlin + t.a, p));
             return scl(x, mk(0.5, 0.5, 0.5));
         }
         /* image_texture, texture.h:115-139 */
         if (t.a < 0) return mk(0, 1, 1);
-        const rtr_image& im = sc.images[t.a];
+        const rtr_image im = ld_const(sc.images, t.a);
         u = clampd(u, 0.0, 1.0);
         v = 1.0 - clampd(v, 0.0, 1.0);
         int i = (int)(u * im.width);
@@ -988,7 +992,7 @@ __device__ __forceinline__ V3 tex_value_slow(const DScene& sc, int ix, Real u, R
         if (i >= im.width) i = im.width - 1;
         if (j >= im.height) j = im.height - 1;
         const Real color_scale = 1.0 / 255.0;
-        const uint8_t* px = sc.image_bytes + im.offset + (size_t)j * 3 * im.width + (size_t)i * 3;
+        const RT_CONST_AS uint8_t* px = as_const(sc.image_bytes + im.offset + (size_t)j * 3 * im.width + (size_t)i * 3);
         return mk(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
     }
     return mk(0, 0, 0);
@@ -1005,7 +1009,7 @@ __device__ __forceinline__ V3 tex_value_slow(const DScene& sc, int ix, Real u, R
 
 template <int MS = RT_MS_FULL>
 RT_DEV V3 tex_value(const DScene& sc, int ix, Real u, Real v, V3 p) {
-    const rtr_texture& t = sc.textures[ix];
+    const rtr_texture t = ld_const(sc.textures, ix);
     if (MS == RT_MS_LEAN || t.type == RTR_TEX_SOLID) return ld3(t.f); /* texture.h:46-48 */
     return tex_value_slow(sc, ix, u, v, p);
 }
@@ -1132,14 +1136,14 @@ RT_DEV Real reflectance(Real cosine, Real ref_idx) { /* material.h:199-203 */
 /* material::emitted(rec, wo): material.h:32-34, :222-227 (front face only) */
 template <int MS = RT_MS_FULL>
 RT_DEV V3 mat_emitted(const DScene& sc, const Hit& rec) {
-    const rtr_material& m = sc.materials[rec.mat];
+    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
     if (m.type == RTR_MAT_DIFFUSE_LIGHT && rec.front) return tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
     return mk(0, 0, 0);
 }
 /* material::emitted(u, v, p): material.h:27-29, :218-220 (two-sided) */
 template <int MS = RT_MS_FULL>
 RT_DEV V3 mat_emitted_legacy(const DScene& sc, const Hit& rec) {
-    const rtr_material& m = sc.materials[rec.mat];
+    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
     if (m.type == RTR_MAT_DIFFUSE_LIGHT) return tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
     return mk(0, 0, 0);
 }
@@ -1180,7 +1184,7 @@ __device__ __forceinline__ bool pbr_sample(const DScene& sc, const rtr_material&
 
 template <int MS = RT_MS_FULL>
 __device__ __forceinline__ bool mat_sample(const DScene& sc, const Hit& rec, V3 wo, BSDFSample& s, uint32_t& rng) {
-    const rtr_material& m = sc.materials[rec.mat];
+    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
     const int type = m.type;
     if (type == RTR_MAT_LAMBERTIAN) { /* material.h:79-90 */
         V3 scatter_direction = add(rec.n, random_unit_vector(rng));
@@ -1226,7 +1230,7 @@ __device__ __forceinline__ bool mat_sample(const DScene& sc, const Hit& rec, V3 
 /* material::eval: base 0 (material.h:48-51), lambertian without hemisphere test (:98-101), PBR (:342) */
 template <int MS = RT_MS_FULL>
 RT_DEV V3 mat_eval(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
-    const rtr_material& m = sc.materials[rec.mat];
+    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
     if (m.type == RTR_MAT_LAMBERTIAN) return divs(tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
     if (MS != RT_MS_LEAN && m.type == RTR_MAT_PBR) return pbr_eval(sc, m, rec, wo, wi);
     return mk(0, 0, 0);
@@ -1234,7 +1238,7 @@ RT_DEV V3 mat_eval(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
 /* material::pdf: base 0 (material.h:54-57), lambertian (:92-96), PBR (:305) */
 template <int MS = RT_MS_FULL>
 RT_DEV Real mat_pdf(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
-    const rtr_material& m = sc.materials[rec.mat];
+    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
     if (m.type == RTR_MAT_LAMBERTIAN) {
         Real cosine = dot(rec.n, unit(wi));
         return cosine < 0 ? 0 : cosine / RT_PI;
@@ -1246,7 +1250,7 @@ RT_DEV Real mat_pdf(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
 template <int MS = RT_MS_FULL>
 __device__ __forceinline__ bool mat_scatter(const DScene& sc, V3 rd, const Hit& rec, V3& attenuation, V3& out_dir,
                                             uint32_t& rng) {
-    const rtr_material& m = sc.materials[rec.mat];
+    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
     const int type = m.type;
     if (type == RTR_MAT_LAMBERTIAN) { /* material.h:103-112 */
         V3 scatter_direction = add(rec.n, random_unit_vector(rng));
@@ -1294,10 +1298,10 @@ struct LightSample {
 struct EnvMap {
     int w, h;
     bool probe;
-    const float* texels;
-    const double* tables;
+    const RT_CONST_AS float* texels;
+    const RT_CONST_AS double* tables;
     /* Distribution1D of map row v (v == h: the marginal): func[n], cdf[n + 1], func_int */
-    RT_DEV const double* dist(int v, int& n) const {
+    RT_DEV const RT_CONST_AS double* dist(int v, int& n) const {
         n = v < h ? w : h;
         return tables + (v < h ? (size_t)v * (2 * w + 2) : (size_t)h * (2 * w + 2));
     }
@@ -1305,12 +1309,12 @@ struct EnvMap {
 RT_DEV EnvMap env_map(const rtr_light& l, const uint8_t* blob) {
     EnvMap m;
     m.w = (int)l.f[0], m.h = (int)l.f[1], m.probe = l.f[2] != 0;
-    m.texels = reinterpret_cast<const float*>(blob + (size_t)l.f[3]);
-    m.tables = reinterpret_cast<const double*>(blob + (size_t)l.f[4]);
+    m.texels = as_const(reinterpret_cast<const float*>(blob + (size_t)l.f[3]));
+    m.tables = as_const(reinterpret_cast<const double*>(blob + (size_t)l.f[4]));
     return m;
 }
-RT_DEV Real dist1d_sample(const double* d, int n, Real u, Real& pdf_out, int& offset) { /* :30-45 */
-    const double *func = d, *cdf = d + n;
+RT_DEV Real dist1d_sample(const RT_CONST_AS double* d, int n, Real u, Real& pdf_out, int& offset) { /* :30-45 */
+    const RT_CONST_AS double *func = d, *cdf = d + n;
     const Real func_int = d[2 * n + 1];
     int lo = 0, hi = n + 1; /* std::lower_bound over cdf[0 .. n] */
     while (lo < hi) {
@@ -1328,7 +1332,7 @@ RT_DEV Real dist1d_sample(const double* d, int n, Real u, Real& pdf_out, int& of
     pdf_out = (func_int > 0) ? func[offset] / func_int : 0;
     return (offset + du) / n;
 }
-RT_DEV Real dist1d_pdf(const double* d, int n, int index) { /* :47-49 */
+RT_DEV Real dist1d_pdf(const RT_CONST_AS double* d, int n, int index) { /* :47-49 */
     const Real func_int = d[2 * n + 1];
     return (func_int > 0) ? d[index] / (func_int * n) : 0;
 }
@@ -1337,7 +1341,7 @@ RT_DEV V3 env_pixel(const EnvMap& m, int i, int j) { /* :276-289 */
     if (i >= m.w) i -= m.w;
     if (j < 0) j = 0;
     if (j >= m.h) j = m.h - 1;
-    const float* t = m.texels + 3 * ((size_t)j * m.w + i);
+    const RT_CONST_AS float* t = m.texels + 3 * ((size_t)j * m.w + i);
     return mk(t[0], t[1], t[2]);
 }
 /* direction -> map coordinates (:233-250, :299-315); returns theta of the polar axis of the mapping */
@@ -1381,9 +1385,9 @@ RT_DEV LightSample env_sample(const EnvMap& m, Real ux, Real uy) { /* :182-224 *
     s.pdf = 0;
     Real pdfs[2];
     int v_idx, u_idx, n;
-    const double* marg = m.dist(m.h, n);
+    const RT_CONST_AS double* marg = m.dist(m.h, n);
     const Real v = dist1d_sample(marg, n, uy, pdfs[1], v_idx);
-    const double* cond = m.dist(v_idx, n);
+    const RT_CONST_AS double* cond = m.dist(v_idx, n);
     const Real u = dist1d_sample(cond, n, ux, pdfs[0], u_idx);
     const Real map_pdf = pdfs[0] * pdfs[1];
     if (map_pdf == 0) return s;
@@ -1418,9 +1422,9 @@ RT_DEV Real env_pdf(const EnvMap& m, V3 direction) { /* :291-331 */
     const int u_idx = (int)clampd((int)(u * m.w), 0, m.w - 1);
     const int v_idx = (int)clampd((int)(v * m.h), 0, m.h - 1);
     int n;
-    const double* cond = m.dist(v_idx, n);
+    const RT_CONST_AS double* cond = m.dist(v_idx, n);
     const Real pu = dist1d_pdf(cond, n, u_idx);
-    const double* marg = m.dist(m.h, n);
+    const RT_CONST_AS double* marg = m.dist(m.h, n);
     const Real map_pdf = pu * dist1d_pdf(marg, n, v_idx);
     return map_pdf * m.w * m.h / (2.0 * RT_PI * RT_PI * sin_theta);
 }
@@ -1546,10 +1550,11 @@ RT_DEV V3 miss_radiance(const DScene& sc, V3 thr, V3 ro, V3 rd, int depth, bool 
         V3 env = mk(0, 0, 0);
         bool found = false;
         for (int k = 0; k < sc.n_lights; ++k) {
-            const int type = sc.lights[k].type;
+            const rtr_light lk = ld_const(sc.lights, k);
+            const int type = lk.type;
             if (type != RTR_LIGHT_ENV_UNIFORM && type != RTR_LIGHT_ENV_MAP) continue;
             V3 le = mk(1, 1, 1); /* environmental_light.h:226-229 */
-            if (type == RTR_LIGHT_ENV_MAP) le = env_Le(env_map(sc.lights[k], sc.image_bytes), rd);
+            if (type == RTR_LIGHT_ENV_MAP) le = env_Le(env_map(lk, sc.image_bytes), rd);
             if (INTEG == RTR_INTEGRATOR_NEE)
                 env = add(env, mul(thr, le)); /* L += throughput * Le, light by light */
             else
@@ -1646,7 +1651,8 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
             const rtr_light l0 = ld_const(sc.lights, 0);
             ls = light_sample<MS>(l0, rec.p, ux, uy, rng, sc.image_bytes);
         } else {
-            ls = light_sample<MS>(sc.lights[light_idx], rec.p, ux, uy, rng, sc.image_bytes);
+            const rtr_light li = ld_const(sc.lights, light_idx);
+            ls = light_sample<MS>(li, rec.p, ux, uy, rng, sc.image_bytes);
         }
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
             V3 f = mat_eval<MS>(sc, rec, wo, ls.wi);

@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_lights(const DScene sc, rtr_
     const long long k = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x;
     if (k >= n) return;
     rtr_light_record r = recs[k];
-    const rtr_light& l = sc.lights[r.light];
+    const rtr_light l = ld_const(sc.lights, r.light);
     uint32_t rng = 0x2545F491u; /* the uniform environment light draws its direction itself */
     LightSample s = light_sample(l, ld3(r.p), r.u[0], r.u[1], rng, sc.image_bytes);
     r.Li[0] = s.Li.x, r.Li[1] = s.Li.y, r.Li[2] = s.Li.z;

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4) wf_extend(const DScene* __restri
             S.hmat[slot] = rec.mat | (rec.front ? (1 << 30) : 0);
             S.flags[slot] = flags | WF_HIT;
             S.rng[slot] = rng;
-            if (SORT) qtype = sc.materials[rec.mat].type;
+            if (SORT) qtype = as_const(sc.materials)[rec.mat].type;
         } while (false);
         if (SORT) wf_block_append<WF_NTYPES>(lds_cnt, cnt, S.q_mat, (size_t)S.n_slots, qtype, slot);
     }
