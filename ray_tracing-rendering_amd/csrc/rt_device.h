@@ -1088,12 +1088,21 @@ RT_DEV V3 pbr_normal(const DScene& sc, const rtr_material& m, const Hit& rec) { 
     }
     return N;
 }
-__device__ __forceinline__ Real pbr_pdf(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
+/* What a hit's material needs from its textures, evaluated ONCE per hit.  The reference re-evaluates
+ * the same pure texture functions inside every eval() / pdf() / sample() call of a bounce (up to eleven
+ * lookups for a PBRMaterial); the values are the same, so are the results. */
+struct MatCtx {
+    int type;
+    Real f0, f1, f2, f3; /* the record's own parameters (metal: albedo + fuzz, dielectric: ir) */
+    V3 albedo;           /* lambertian / diffuse_light / isotropic: value of tex[0]; PBR: base colour */
+    V3 N;                /* PBR: shading normal (material.h:247-261) */
+    Real rough, metal;   /* PBR: roughness clamped to [0.01, 1] (:264,327,368), metallic */
+};
+__device__ __forceinline__ Real pbr_pdf(const MatCtx& c, V3 wo, V3 wi) {
     /* material.h:305-340 */
-    V3 N = pbr_normal(sc, m, rec);
+    const V3 N = c.N;
     if (dot(N, wi) <= 0) return 0;
-    Real rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
-    rough = clampd(rough, 0.01, 1.0);
+    const Real rough = c.rough;
     Real pdf_diff = dot(N, wi) / RT_PI;
     V3 H = unit(add(wo, wi));
     Real D = distribution_ggx(N, H, rough);
@@ -1102,16 +1111,14 @@ __device__ __forceinline__ Real pbr_pdf(const DScene& sc, const rtr_material& m,
     Real pdf_spec = (D * NdotH) / (4.0 * HdotV + 0.0001);
     return 0.5 * pdf_diff + 0.5 * pdf_spec;
 }
-__device__ __forceinline__ V3 pbr_eval(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, V3 wi) {
+__device__ __forceinline__ V3 pbr_eval(const MatCtx& c, V3 wo, V3 wi) {
     /* material.h:342-396 */
-    V3 N = pbr_normal(sc, m, rec);
+    const V3 N = c.N;
     Real NdotL = dot(N, wi);
     Real NdotV = dot(N, wo);
     if (NdotL <= 0 || NdotV <= 0) return mk(0, 0, 0);
-    Real rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
-    Real metal = tex_scalar(sc, m.tex[2], rec.u, rec.v, rec.p);
-    V3 base_color = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
-    rough = clampd(rough, 0.01, 1.0);
+    const Real rough = c.rough, metal = c.metal;
+    const V3 base_color = c.albedo;
     V3 H = unit(add(wo, wi));
     V3 F0 = mk(0.04, 0.04, 0.04);
     V3 metal_vec = mk(metal, metal, metal);
@@ -1133,73 +1140,84 @@ RT_DEV Real reflectance(Real cosine, Real ref_idx) { /* material.h:199-203 */
     return r0 + (1 - r0) * pow5(1 - cosine);
 }
 
-/* material::emitted(rec, wo): material.h:32-34, :222-227 (front face only) */
 template <int MS = RT_MS_FULL>
-RT_DEV V3 mat_emitted(const DScene& sc, const Hit& rec) {
+RT_DEV MatCtx mat_prepare(const DScene& sc, const Hit& rec) {
     const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
-    if (m.type == RTR_MAT_DIFFUSE_LIGHT && rec.front) return tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
+    MatCtx c;
+    c.type = m.type;
+    c.f0 = m.f[0], c.f1 = m.f[1], c.f2 = m.f[2], c.f3 = m.f[3];
+    c.albedo = mk(0, 0, 0), c.N = rec.n, c.rough = 0, c.metal = 0;
+    if (c.type == RTR_MAT_LAMBERTIAN || c.type == RTR_MAT_DIFFUSE_LIGHT) {
+        c.albedo = tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
+    } else if (MS != RT_MS_LEAN && c.type == RTR_MAT_ISOTROPIC) {
+        c.albedo = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    } else if (MS != RT_MS_LEAN && c.type == RTR_MAT_PBR) {
+        c.N = pbr_normal(sc, m, rec);
+        c.rough = clampd(tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p), 0.01, 1.0);
+        c.metal = tex_scalar(sc, m.tex[2], rec.u, rec.v, rec.p);
+        c.albedo = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+    }
+    return c;
+}
+
+/* material::emitted(rec, wo): material.h:32-34, :222-227 (front face only) */
+RT_DEV V3 mat_emitted(const MatCtx& c, const Hit& rec) {
+    if (c.type == RTR_MAT_DIFFUSE_LIGHT && rec.front) return c.albedo;
     return mk(0, 0, 0);
 }
 /* material::emitted(u, v, p): material.h:27-29, :218-220 (two-sided) */
-template <int MS = RT_MS_FULL>
-RT_DEV V3 mat_emitted_legacy(const DScene& sc, const Hit& rec) {
-    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
-    if (m.type == RTR_MAT_DIFFUSE_LIGHT) return tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
+RT_DEV V3 mat_emitted_legacy(const MatCtx& c) {
+    if (c.type == RTR_MAT_DIFFUSE_LIGHT) return c.albedo;
     return mk(0, 0, 0);
 }
 
-/* PBRMaterial::sample (material.h:245-303), out of line like pbr_eval / pbr_pdf */
-__device__ __forceinline__ bool pbr_sample(const DScene& sc, const rtr_material& m, const Hit& rec, V3 wo, BSDFSample& s,
-                                        uint32_t& rng) {
-    {
-        V3 N = pbr_normal(sc, m, rec);
-        Real rough = tex_scalar(sc, m.tex[1], rec.u, rec.v, rec.p);
-        rough = clampd(rough, 0.01, 1.0);
-        if (rng_next(rng) < 0.5) {
-            Onb uvw = onb_from_w(N);
-            Real r1 = rng_next(rng);
-            Real r2 = rng_next(rng);
-            Real a = rough * rough;
-            Real phi = 2.0 * RT_PI * r1;
-            Real cos_theta = __builtin_sqrt((1.0 - r2) / (1.0 + (a * a - 1.0) * r2));
-            Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
-            V3 H_local = mk(sin_theta * cos(phi), sin_theta * sin(phi), cos_theta);
-            V3 H = onb_local(uvw, H_local);
-            V3 L = reflect(neg(wo), H);
-            if (dot(N, L) <= 0) return false;
-            s.wi = L;
-        } else {
-            Onb uvw = onb_from_w(N);
-            V3 L = onb_local(uvw, random_cosine_direction(rng));
-            if (dot(N, L) <= 0) L = N;
-            s.wi = unit(L);
-        }
-        s.is_specular = false;
-        s.pdf = pbr_pdf(sc, m, rec, wo, s.wi);
-        s.f = pbr_eval(sc, m, rec, wo, s.wi);
-        if (s.pdf < 1e-6) return false;
-        return true;
+/* PBRMaterial::sample (material.h:245-303) */
+__device__ __forceinline__ bool pbr_sample(const MatCtx& c, V3 wo, BSDFSample& s, uint32_t& rng) {
+    const V3 N = c.N;
+    const Real rough = c.rough;
+    if (rng_next(rng) < 0.5) {
+        Onb uvw = onb_from_w(N);
+        Real r1 = rng_next(rng);
+        Real r2 = rng_next(rng);
+        Real a = rough * rough;
+        Real phi = 2.0 * RT_PI * r1;
+        Real cos_theta = __builtin_sqrt((1.0 - r2) / (1.0 + (a * a - 1.0) * r2));
+        Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+        V3 H_local = mk(sin_theta * cos(phi), sin_theta * sin(phi), cos_theta);
+        V3 H = onb_local(uvw, H_local);
+        V3 L = reflect(neg(wo), H);
+        if (dot(N, L) <= 0) return false;
+        s.wi = L;
+    } else {
+        Onb uvw = onb_from_w(N);
+        V3 L = onb_local(uvw, random_cosine_direction(rng));
+        if (dot(N, L) <= 0) L = N;
+        s.wi = unit(L);
     }
+    s.is_specular = false;
+    s.pdf = pbr_pdf(c, wo, s.wi);
+    s.f = pbr_eval(c, wo, s.wi);
+    if (s.pdf < 1e-6) return false;
+    return true;
 }
 
 template <int MS = RT_MS_FULL>
-__device__ __forceinline__ bool mat_sample(const DScene& sc, const Hit& rec, V3 wo, BSDFSample& s, uint32_t& rng) {
-    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
-    const int type = m.type;
+__device__ __forceinline__ bool mat_sample(const MatCtx& c, const Hit& rec, V3 wo, BSDFSample& s, uint32_t& rng) {
+    const int type = c.type;
     if (type == RTR_MAT_LAMBERTIAN) { /* material.h:79-90 */
         V3 scatter_direction = add(rec.n, random_unit_vector(rng));
         if (near_zero(scatter_direction)) scatter_direction = rec.n;
         s.wi = unit(scatter_direction);
         s.pdf = dot(rec.n, s.wi) / RT_PI;
-        s.f = divs(tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
+        s.f = divs(c.albedo, RT_PI);
         s.is_specular = false;
         return true;
     }
     if (MS == RT_MS_LEAN) return false; /* diffuse_light::sample (material.h:213-216) */
     if (type == RTR_MAT_METAL) { /* material.h:123-131 */
         V3 reflected = reflect(unit(neg(wo)), rec.n);
-        s.wi = unit(add(reflected, scl(m.f[3], random_in_unit_sphere(rng))));
-        s.f = ld3(m.f);
+        s.wi = unit(add(reflected, scl(c.f3, random_in_unit_sphere(rng))));
+        s.f = mk(c.f0, c.f1, c.f2);
         s.pdf = 1.0;
         s.is_specular = true;
         return dot(s.wi, rec.n) > 0;
@@ -1208,7 +1226,7 @@ __device__ __forceinline__ bool mat_sample(const DScene& sc, const Hit& rec, V3 
         s.f = mk(1.0, 1.0, 1.0);
         s.is_specular = true;
         s.pdf = 1.0;
-        Real ir = m.f[0];
+        Real ir = c.f0;
         Real refraction_ratio = rec.front ? (1.0 / ir) : ir;
         V3 unit_direction = neg(wo);
         Real cos_theta = __builtin_fmin(dot(neg(unit_direction), rec.n), 1.0);
@@ -1223,52 +1241,49 @@ __device__ __forceinline__ bool mat_sample(const DScene& sc, const Hit& rec, V3 
         }
         return true;
     }
-    if (type == RTR_MAT_PBR) return pbr_sample(sc, m, rec, wo, s, rng);
+    if (type == RTR_MAT_PBR) return pbr_sample(c, wo, s, rng);
     return false; /* diffuse_light (material.h:213-216), isotropic (base class, :42-45) */
 }
 
 /* material::eval: base 0 (material.h:48-51), lambertian without hemisphere test (:98-101), PBR (:342) */
 template <int MS = RT_MS_FULL>
-RT_DEV V3 mat_eval(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
-    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
-    if (m.type == RTR_MAT_LAMBERTIAN) return divs(tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p), RT_PI);
-    if (MS != RT_MS_LEAN && m.type == RTR_MAT_PBR) return pbr_eval(sc, m, rec, wo, wi);
+RT_DEV V3 mat_eval(const MatCtx& c, V3 wo, V3 wi) {
+    if (c.type == RTR_MAT_LAMBERTIAN) return divs(c.albedo, RT_PI);
+    if (MS != RT_MS_LEAN && c.type == RTR_MAT_PBR) return pbr_eval(c, wo, wi);
     return mk(0, 0, 0);
 }
 /* material::pdf: base 0 (material.h:54-57), lambertian (:92-96), PBR (:305) */
 template <int MS = RT_MS_FULL>
-RT_DEV Real mat_pdf(const DScene& sc, const Hit& rec, V3 wo, V3 wi) {
-    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
-    if (m.type == RTR_MAT_LAMBERTIAN) {
+RT_DEV Real mat_pdf(const MatCtx& c, const Hit& rec, V3 wo, V3 wi) {
+    if (c.type == RTR_MAT_LAMBERTIAN) {
         Real cosine = dot(rec.n, unit(wi));
         return cosine < 0 ? 0 : cosine / RT_PI;
     }
-    if (MS != RT_MS_LEAN && m.type == RTR_MAT_PBR) return pbr_pdf(sc, m, rec, wo, wi);
+    if (MS != RT_MS_LEAN && c.type == RTR_MAT_PBR) return pbr_pdf(c, wo, wi);
     return 0.0;
 }
 /* legacy material::scatter(r_in, rec, attenuation, scattered): new ray = (rec.p, dir, r_in.time) */
 template <int MS = RT_MS_FULL>
-__device__ __forceinline__ bool mat_scatter(const DScene& sc, V3 rd, const Hit& rec, V3& attenuation, V3& out_dir,
+__device__ __forceinline__ bool mat_scatter(const MatCtx& c, V3 rd, const Hit& rec, V3& attenuation, V3& out_dir,
                                             uint32_t& rng) {
-    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
-    const int type = m.type;
+    const int type = c.type;
     if (type == RTR_MAT_LAMBERTIAN) { /* material.h:103-112 */
         V3 scatter_direction = add(rec.n, random_unit_vector(rng));
         if (near_zero(scatter_direction)) scatter_direction = rec.n;
         out_dir = scatter_direction;
-        attenuation = tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
+        attenuation = c.albedo;
         return true;
     }
     if (MS == RT_MS_LEAN) return false; /* diffuse_light::scatter (material.h:229-232) */
     if (type == RTR_MAT_METAL) { /* material.h:133-140 */
         V3 reflected = reflect(unit(rd), rec.n);
-        out_dir = add(reflected, scl(m.f[3], random_in_unit_sphere(rng)));
-        attenuation = ld3(m.f);
+        out_dir = add(reflected, scl(c.f3, random_in_unit_sphere(rng)));
+        attenuation = mk(c.f0, c.f1, c.f2);
         return dot(out_dir, rec.n) > 0;
     }
     if (type == RTR_MAT_DIELECTRIC) { /* material.h:176-193 */
         attenuation = mk(1.0, 1.0, 1.0);
-        Real ir = m.f[0];
+        Real ir = c.f0;
         Real refraction_ratio = rec.front ? (1.0 / ir) : ir;
         V3 unit_direction = unit(rd);
         Real cos_theta = __builtin_fmin(dot(neg(unit_direction), rec.n), 1.0);
@@ -1282,7 +1297,7 @@ __device__ __forceinline__ bool mat_scatter(const DScene& sc, V3 rd, const Hit& 
     }
     if (type == RTR_MAT_ISOTROPIC) { /* geometry/constant_medium.h:19-24 */
         out_dir = random_in_unit_sphere(rng);
-        attenuation = tex_value(sc, m.tex[0], rec.u, rec.v, rec.p);
+        attenuation = c.albedo;
         return true;
     }
     return false; /* diffuse_light (material.h:229-232), PBRMaterial (base class, :66-69) */
@@ -1616,17 +1631,18 @@ struct ShadowReq {
  *                       without MIS weight and with the per-channel rescale of :133-139, no fallback)
  *   RTR_INTEGRATOR_PBR  pbr_path_integrator.h:38-68     (emission unweighted, no light sample, no fallback) */
 template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS>
-RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, ShadowReq& rq) {
+RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, const MatCtx& mc, V3 wo, uint32_t& rng,
+                        ShadowReq& rq) {
     const bool have_lights = sc.n_lights > 0;
     rq.valid = false;
     if (INTEG == RTR_INTEGRATOR_PBR) {
-        ps.L = add(ps.L, mul(ps.thr, mat_emitted<MS>(sc, rec))); /* pbr_path_integrator.h:40-41 */
+        ps.L = add(ps.L, mul(ps.thr, mat_emitted(mc, rec))); /* pbr_path_integrator.h:40-41 */
         return;
     }
     if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:56-59 */
-        if (ps.depth == 0 || ps.specular_bounce) ps.L = add(ps.L, mul(ps.thr, mat_emitted<MS>(sc, rec)));
+        if (ps.depth == 0 || ps.specular_bounce) ps.L = add(ps.L, mul(ps.thr, mat_emitted(mc, rec)));
     } else {
-        V3 emitted = mat_emitted<MS>(sc, rec);
+        V3 emitted = mat_emitted(mc, rec);
         if (len2(emitted) > 0) { /* mis_path_integrator.h:72-94 */
             V3 L_emit;
             if (ps.depth == 0 || ps.specular_bounce) {
@@ -1655,7 +1671,7 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
             ls = light_sample<MS>(li, rec.p, ux, uy, rng, sc.image_bytes);
         }
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
-            V3 f = mat_eval<MS>(sc, rec, wo, ls.wi);
+            V3 f = mat_eval<MS>(mc, wo, ls.wi);
             Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));
             V3 L_direct;
             if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:125-139 */
@@ -1667,7 +1683,7 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
             } else if (ls.is_delta) { /* mis_path_integrator.h:219-221: no BSDF sample can hit a delta light */
                 L_direct = divs(scl(cos_theta, mul(f, ls.Li)), light_select_pdf);
             } else { /* mis_path_integrator.h:222-229 */
-                Real bsdf_pdf = mat_pdf<MS>(sc, rec, wo, ls.wi);
+                Real bsdf_pdf = mat_pdf<MS>(mc, rec, wo, ls.wi);
                 Real lpdf = ls.pdf * light_select_pdf;
                 Real mis_weight = power_heuristic(lpdf, bsdf_pdf);
                 L_direct = divs(scl(mis_weight, scl(cos_theta, mul(f, ls.Li))), lpdf);
@@ -1683,12 +1699,13 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
 /* second half (mis_path_integrator.h:105-146): BSDF sampling with the legacy scatter()
  * fallback (MIS only), throughput update, Russian roulette.  Returns false when the path ends. */
 template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS>
-RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, uint32_t& rng, int rr_start) {
+RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, const MatCtx& mc, V3 wo, uint32_t& rng,
+                        int rr_start) {
     BSDFSample bs;
-    if (!mat_sample<MS>(sc, rec, wo, bs, rng)) { /* :106-118 */
+    if (!mat_sample<MS>(mc, rec, wo, bs, rng)) { /* :106-118 */
         if (INTEG != RTR_INTEGRATOR_MIS) return false; /* pbr_path_integrator.h:44-46, direct_light_integrator.h:67-69 */
         V3 attenuation, ndir;
-        if (!mat_scatter<MS>(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+        if (!mat_scatter<MS>(mc, ps.rd, rec, attenuation, ndir, rng)) return false;
         ps.thr = mul(ps.thr, attenuation);
         ps.ro = rec.p, ps.rd = ndir;
         ps.specular_bounce = false;
@@ -1716,9 +1733,10 @@ RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, V3 wo, 
  * legacy scatter(), roulette clamp [0.005, 0.95] tested before the ray moves on. */
 template <int MS = RT_MS_FULL>
 RT_DEV bool shade_rr(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& rng, int rr_start) {
-    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy<MS>(sc, rec)));
+    const MatCtx mc = mat_prepare<MS>(sc, rec);
+    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy(mc)));
     V3 attenuation, ndir;
-    if (!mat_scatter<MS>(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+    if (!mat_scatter<MS>(mc, ps.rd, rec, attenuation, ndir, rng)) return false;
     ps.thr = mul(ps.thr, attenuation);
     if (ps.depth >= rr_start) {
         Real p_survive = clampd(max3(ps.thr), 0.005, 0.95);
@@ -1734,9 +1752,10 @@ RT_DEV bool shade_rr(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& 
  * rounding (<= 1e-15 relative).  No roulette; depth limited by max_depth. */
 template <int MS = RT_MS_FULL>
 RT_DEV bool shade_path(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& rng) {
-    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy<MS>(sc, rec)));
+    const MatCtx mc = mat_prepare<MS>(sc, rec);
+    ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy(mc)));
     V3 attenuation, ndir;
-    if (!mat_scatter<MS>(sc, ps.rd, rec, attenuation, ndir, rng)) return false;
+    if (!mat_scatter<MS>(mc, ps.rd, rec, attenuation, ndir, rng)) return false;
     ps.thr = mul(ps.thr, attenuation);
     ps.ro = rec.p, ps.rd = ndir;
     return true;
@@ -1768,12 +1787,13 @@ __device__ __forceinline__ bool bounce(const DScene& sc, PathState& ps, uint32_t
     } else {
         V3 wo = neg(unit(ps.rd));
         ShadowReq rq;
-        shade_a_mis<RT_MS_FULL, INTEG>(sc, ps, rec, wo, rng, rq);
+        const MatCtx mc = mat_prepare<RT_MS_FULL>(sc, rec);
+        shade_a_mis<RT_MS_FULL, INTEG>(sc, ps, rec, mc, wo, rng, rq);
         if (rq.valid) {
             ++cnt.shadow;
             if (!cast_shadow<TRAV>(sc, rec.p, rq.wi, rq.tmax, rng, st)) ps.L = add(ps.L, rq.contrib);
         } /* else the reference adds clamp_radiance(throughput * 0) = +0 (:99-103): no effect */
-        go = shade_b_mis<RT_MS_FULL, INTEG>(sc, ps, rec, wo, rng, rr_start);
+        go = shade_b_mis<RT_MS_FULL, INTEG>(sc, ps, rec, mc, wo, rng, rr_start);
     }
     if (!go) return false;
     return ++ps.depth < max_depth;

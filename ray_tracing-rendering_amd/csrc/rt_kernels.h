@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                     } else {
                         const V3 wo = neg(unit(ps.rd));
                         ShadowReq rq;
-                        shade_a_mis<MS, INTEG>(sc, ps, rec, wo, rng, rq);
+                        MatCtx mc = mat_prepare<MS>(sc, rec);
+                        shade_a_mis<MS, INTEG>(sc, ps, rec, mc, wo, rng, rq);
                         if (TRAV == RT_TRAV_PROGRAM) {
                             /* media draw inside the shadow cast: it keeps its place between the light
                              * sample and the BSDF sample (mis_path_integrator.h:96-106) */
@@ -196,6 +197,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                                 pk.set(PK_NSHADOW, pk.get(PK_NSHADOW) + 1.0);
                                 if (!cast_shadow<TRAV>(sc, rec.p, rq.wi, rq.tmax, rng, st))
                                     pk.set3(PK_L, add(pk.get3(PK_L), rq.contrib));
+                                mc = mat_prepare<MS>(sc, rec); /* cheaper than keeping it in registers across the cast */
                             }
                         } else if (rq.valid) { /* parked until the shadow ray is cast */
                             pending = true;
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                             pk.set(PK_STMAX, rq.tmax);
                             pk.set3(PK_CONTRIB, rq.contrib);
                         }
-                        go = shade_b_mis<MS, INTEG>(sc, ps, rec, wo, rng, P.rr_start);
+                        go = shade_b_mis<MS, INTEG>(sc, ps, rec, mc, wo, rng, P.rr_start);
                     }
                     ps.ro = rec.p; /* next ray origin and shadow ray origin */
                     pk.set3(PK_THR, ps.thr);
@@ -329,17 +331,18 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_materials(const DScene sc, r
     uint32_t rng = r.rng_in;
     BSDFSample bs;
     bs.wi = mk(0, 0, 0), bs.f = mk(0, 0, 0), bs.pdf = 0, bs.is_specular = false, bs.is_transmission = false;
-    const bool ok = mat_sample(sc, rec, wo, bs, rng);
+    const MatCtx mc = mat_prepare(sc, rec);
+    const bool ok = mat_sample(mc, rec, wo, bs, rng);
     r.rng_out = rng;
     r.sample_ok = ok, r.is_specular = bs.is_specular, r.pad = 0;
     r.is_transmission = bs.is_transmission;
     r.s_wi[0] = bs.wi.x, r.s_wi[1] = bs.wi.y, r.s_wi[2] = bs.wi.z;
     r.s_f[0] = bs.f.x, r.s_f[1] = bs.f.y, r.s_f[2] = bs.f.z;
     r.s_pdf = bs.pdf;
-    const V3 e = mat_eval(sc, rec, wo, wi);
+    const V3 e = mat_eval(mc, wo, wi);
     r.eval[0] = e.x, r.eval[1] = e.y, r.eval[2] = e.z;
-    r.pdf = mat_pdf(sc, rec, wo, wi);
-    const V3 em = mat_emitted(sc, rec);
+    r.pdf = mat_pdf(mc, rec, wo, wi);
+    const V3 em = mat_emitted(mc, rec);
     r.emitted[0] = em.x, r.emitted[1] = em.y, r.emitted[2] = em.z;
     recs[k] = r;
 }

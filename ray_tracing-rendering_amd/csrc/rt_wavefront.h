@@ -328,10 +328,11 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? 4 : 2) wf_shade(
         int extra = flags & WF_SHADOW; /* phase 2 keeps what phase 1 requested */
         if (INTEG == RTR_INTEGRATOR_MIS) {
             const V3 wo = neg(unit(ps.rd));
+            const MatCtx mc = mat_prepare<MS>(sc, rec);
             if (PHASE != 2) {
                 const V3 L0 = ps.L;
                 ShadowReq rq;
-                shade_a_mis<MS>(sc, ps, rec, wo, rng, rq);
+                shade_a_mis<MS>(sc, ps, rec, mc, wo, rng, rq);
                 if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
                 extra = 0;
                 if (rq.valid) {
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? 4 : 2) wf_shade(
                 if (extra) S.flags[slot] = flags | WF_SHADOW;
                 continue;
             }
-            go = shade_b_mis<MS>(sc, ps, rec, wo, rng, P.rr_start);
+            go = shade_b_mis<MS>(sc, ps, rec, mc, wo, rng, P.rr_start);
         } else {
             const V3 L0 = ps.L;
             go = shade_rr<MS>(sc, ps, rec, rng, P.rr_start);
