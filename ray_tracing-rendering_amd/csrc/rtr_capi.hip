@@ -593,6 +593,11 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
             }
             for (const auto& g : groups) {
                 const std::vector<int>& v = g.second;
+                if (v.size() > 512) { /* a huge coplanar set (tiled floor): flag all rather than test every pair */
+                    for (int r : v) prims[r].reserved |= RT_TIE_FLAG;
+                    any_tie = true;
+                    continue;
+                }
                 for (size_t x = 0; x < v.size(); ++x)
                     for (size_t y = x + 1; y < v.size(); ++y) {
                         rtr_node &p = prims[v[x]], &q = prims[v[y]];
