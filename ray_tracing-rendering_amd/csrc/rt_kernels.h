@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
         V3 acc = mk(0, 0, 0);
         while (!done) {
             if (fresh) { /* renderer.h:73-75 under the per-sample seed */
-                if (__hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if ((s & 7) == 0 && __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                 rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
                 const Real u = (i + rng_next(rng)) / (P.W - 1);
                 const Real v = (j + rng_next(rng)) / (P.H - 1);
@@ -225,7 +225,9 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                 pk.set3(PK_ACC, add(pk.get3(PK_ACC), pk.get3(PK_L))); /* renderer.h:77-78 */
                 ++n_samples;
                 ++s;
-                done = s >= s_end || __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                /* rtr_cancel(): polled every 8th sample of a pixel -- the load is a dependent memory round
+                 * trip in the lane's critical path */
+                done = s >= s_end || ((s & 7) == 0 && __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (!done) begin_sample();
             }
         }
