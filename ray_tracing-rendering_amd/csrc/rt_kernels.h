@@ -79,7 +79,16 @@ struct Park {
     RT_DEV double get(int k) const { return base[k * RTR_BLOCK]; }
     RT_DEV void set(int k, double v) const { base[k * RTR_BLOCK] = v; }
 };
-enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_CONTRIB = 9, PK_PDF = 12, PK_SWI = 13, PK_STMAX = 16, PK_NCLOSEST = 17, PK_NSHADOW = 18 };
+enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_PDF = 9, PK_NCLOSEST = 10, PK_NSHADOW = 11, /* every variant */
+       PK_CONTRIB = 12, PK_SWI = 15, PK_STMAX = 18 };                                       /* deferred shadow ray only */
+/* words a variant parks: the deferred shadow request exists only where the shadow ray is cast after the
+ * BSDF sample (MIS-type integrators on scenes without media); fewer words = more workgroups per CU where
+ * LDS, not registers, is the limit (the lean RR kernel: 92 VGPRs) */
+constexpr int park_words(int integ, int trav) {
+    return (integ == RTR_INTEGRATOR_RR || integ == RTR_INTEGRATOR_PATH || trav == RT_TRAV_PROGRAM || trav == RT_TRAV_MEDIA)
+               ? 12
+               : RT_PARK_WORDS;
+}
 
 template <int INTEG, int TRAV, int MS>
 __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))

@@ -349,7 +349,7 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in) {
     /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
     const int trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
     const int stack_words = (int)(stack_bytes(c, trav) / (RTR_BLOCK * sizeof(int)));
-    const size_t lds = stack_bytes(c, trav) + (size_t)RT_PARK_WORDS * RTR_BLOCK * sizeof(double);
+    const size_t lds = stack_bytes(c, trav) + (size_t)park_words(integrator, trav) * RTR_BLOCK * sizeof(double);
     const DScene* dsc = static_cast<const DScene*>(c->b_dscene.p);
     const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
     const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
