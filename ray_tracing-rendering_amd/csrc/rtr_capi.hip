@@ -762,10 +762,8 @@ int rtr_render_host(rtr_context* c, const rtr_render_params* p, double* h_rgb, i
     hipError_t e = hipMalloc(&d, bytes);
     if (e != hipSuccess) return fail(c, RTR_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     /* pixels of tiles this call does not own keep the caller's values */
-    hipError_t ce = hipSuccess;
-    for (int r = 0; r < h && ce == hipSuccess; ++r)
-        ce = hipMemcpyAsync(static_cast<double*>(d) + (size_t)r * w * 3, h_rgb + (size_t)r * row_stride * 3,
-                            (size_t)w * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    hipError_t ce = hipMemcpy2DAsync(d, (size_t)w * 3 * sizeof(double), h_rgb, (size_t)row_stride * 3 * sizeof(double),
+                                     (size_t)w * 3 * sizeof(double), h, hipMemcpyHostToDevice, c->stream);
     int rc = ce == hipSuccess ? rtr_render_device(c, p, static_cast<double*>(d), w, 1)
                               : fail(c, RTR_ERR_DEVICE, hipGetErrorString(ce));
     if (rc == RTR_OK || rc == RTR_ERR_CANCELLED) {
