@@ -435,6 +435,8 @@ inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, bool sort, std
 
 template <typename K>
 inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
+    if (bytes > 160 * 1024)
+        return wf_fail(err, RTR_ERR_UNSUPPORTED, "this traversal of the scene needs a deeper stack than 160 KiB of LDS holds");
     if (bytes > 64 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)bytes));

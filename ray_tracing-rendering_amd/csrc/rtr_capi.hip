@@ -156,6 +156,24 @@ struct Validator {
         }
     }
 
+    /* children of a node by position (no per-visit copies: a hittable_list can hold a million of them) */
+    int child_count(const rtr_node& n) const {
+        switch (n.type) {
+        case RTR_NODE_BVH: return 2;
+        case RTR_NODE_LIST: return n.b;
+        case RTR_NODE_TRANSLATE:
+        case RTR_NODE_ROTATE_Y:
+        case RTR_NODE_FLIP_FACE:
+        case RTR_NODE_MEDIUM: return 1;
+        default: return 0;
+        }
+    }
+    int child_at(const rtr_node& n, int k) const {
+        if (n.type == RTR_NODE_BVH) return k == 0 ? n.a : n.b;
+        if (n.type == RTR_NODE_LIST) return s->list_children[n.a + k];
+        return n.a;
+    }
+
     /* iterative post-order DFS over the hittable DAG */
     bool walk(int root) {
         struct Frame {
@@ -164,36 +182,35 @@ struct Validator {
         std::vector<Frame> stk;
         stk.push_back({root, 0});
         state[root] = 1;
-        std::vector<int> kids;
         while (!stk.empty()) {
             Frame& f = stk.back();
             const rtr_node& n = s->nodes[f.node];
-            kids.clear();
-            switch (n.type) {
-            case RTR_NODE_BVH: kids = {n.a, n.b}; break;
-            case RTR_NODE_LIST:
-                if (n.a < 0 || n.b < 0 || (int64_t)n.a + n.b > s->n_list_children)
-                    return bad(RTR_ERR_INVALID, "hittable_list children out of range");
-                kids.assign(s->list_children + n.a, s->list_children + n.a + n.b);
-                break;
-            case RTR_NODE_TRANSLATE:
-            case RTR_NODE_ROTATE_Y:
-            case RTR_NODE_FLIP_FACE: kids = {n.a}; break;
-            case RTR_NODE_MEDIUM:
-                if (!material_ok(n.b)) return false;
-                kids = {n.a};
-                break;
-            case RTR_NODE_SPHERE:
-            case RTR_NODE_MOVING_SPHERE:
-            case RTR_NODE_XY_RECT:
-            case RTR_NODE_XZ_RECT:
-            case RTR_NODE_YZ_RECT:
-                if (!material_ok(n.a)) return false;
-                break;
-            default: return bad(RTR_ERR_UNSUPPORTED, "unknown hittable node type");
+            if (f.next == 0) { /* first visit: check the record itself */
+                switch (n.type) {
+                case RTR_NODE_BVH:
+                case RTR_NODE_TRANSLATE:
+                case RTR_NODE_ROTATE_Y:
+                case RTR_NODE_FLIP_FACE: break;
+                case RTR_NODE_LIST:
+                    if (n.a < 0 || n.b < 0 || (int64_t)n.a + n.b > s->n_list_children)
+                        return bad(RTR_ERR_INVALID, "hittable_list children out of range");
+                    break;
+                case RTR_NODE_MEDIUM:
+                    if (!material_ok(n.b)) return false;
+                    break;
+                case RTR_NODE_SPHERE:
+                case RTR_NODE_MOVING_SPHERE:
+                case RTR_NODE_XY_RECT:
+                case RTR_NODE_XZ_RECT:
+                case RTR_NODE_YZ_RECT:
+                    if (!material_ok(n.a)) return false;
+                    break;
+                default: return bad(RTR_ERR_UNSUPPORTED, "unknown hittable node type");
+                }
             }
-            if (f.next < (int)kids.size()) {
-                int k = kids[f.next++];
+            const int m = child_count(n);
+            if (f.next < m) {
+                int k = child_at(n, f.next++);
                 if (!node_ix(k)) return bad(RTR_ERR_INVALID, "hittable child index out of range");
                 if (state[k] == 1) return bad(RTR_ERR_INVALID, "hittable graph has a cycle");
                 if (state[k] == 0) {
@@ -206,16 +223,16 @@ struct Validator {
             const int me = f.node;
             int u = 0, d = 0;
             char md = 0;
-            const int m = (int)kids.size();
-            for (int k : kids) {
-                d = std::max(d, depth[k]);
-                md |= media[k];
+            for (int k = 0; k < m; ++k) {
+                const int ck = child_at(n, k);
+                d = std::max(d, depth[ck]);
+                md |= media[ck];
             }
             switch (n.type) {
             case RTR_NODE_BVH: u = std::max(2, std::max(1 + need[n.a], need[n.b])); break;
             case RTR_NODE_LIST:
                 u = m;
-                for (int k = 0; k < m; ++k) u = std::max(u, (m - 1 - k) + need[kids[k]]);
+                for (int k = 0; k < m; ++k) u = std::max(u, (m - 1 - k) + need[child_at(n, k)]);
                 break;
             case RTR_NODE_TRANSLATE: u = RT_FRAME_TRANSLATE + std::max(1, need[n.a]); break;
             case RTR_NODE_ROTATE_Y: u = RT_FRAME_ROTATE + std::max(1, need[n.a]); break;
@@ -339,6 +356,10 @@ size_t stack_bytes(const rtr_context* c, int trav) {
 
 template <typename K>
 int set_lds(rtr_context* c, K kernel, size_t bytes) {
+    /* the per-lane traversal stack lives in LDS: a graph that needs more than the CU has (e.g. the
+     * reference-order walk of a hittable_list with thousands of direct children) cannot run that way */
+    if (bytes > 160 * 1024)
+        return fail(c, RTR_ERR_UNSUPPORTED, "this traversal of the scene needs a deeper stack than 160 KiB of LDS holds");
     if (bytes > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -542,8 +563,6 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     rtr_scene_info info{};
     int rc = v.run(&info);
     if (rc) return fail(c, rc, "scene rejected: " + v.msg);
-    if ((size_t)(info.stack_words + 64) * RTR_BLOCK * sizeof(int) > 160 * 1024)
-        return fail(c, RTR_ERR_UNSUPPORTED, "scene needs a deeper traversal stack than 160 KiB of LDS holds");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;

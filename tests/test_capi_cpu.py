@@ -69,6 +69,26 @@ def test_hollow_spheres_keep_the_reference_walk(sid, inverted):
     assert info["fast_ok"] == (inverted == 0)
 
 
+def test_large_flat_list_compiles():
+    """A hittable_list with 50 000 direct children (no bvh_node around it): the reference-order walk would
+    need a 50 000-word stack per lane, the compiled traversal a box tree of depth ~16 -- upload must
+    accept the scene (the LDS limit is checked per traversal at launch) and compile it in linear-ish time."""
+    base = G.scene(23)
+    n = 50_000
+    rng = np.random.default_rng(3)
+    nodes = np.zeros(n + 1, dtype=A.NODE_DTYPE)
+    nodes["type"][0], nodes["a"][0], nodes["b"][0] = A.NODE_LIST, 0, n
+    nodes["type"][1:] = A.NODE_SPHERE
+    nodes["a"][1:] = rng.integers(0, len(base.materials), n)
+    nodes["f"][1:, 0:3] = rng.uniform(-4.0, 4.0, (n, 3))
+    nodes["f"][1:, 3] = 0.05
+    sc = rtr.Scene(0, nodes, np.arange(1, n + 1, dtype=np.int32), base.materials, base.textures, base.perlin,
+                   base.images, base.image_bytes, base.lights, base.camera, base.background)
+    info = rtr.native.validate_scene(sc)
+    assert info["fast_ok"] and info["fast_refs"] == n and info["stack_words"] == n
+    assert 8 <= info["fast_stack_words"] <= 40
+
+
 def _mutated(sid, fn):
     sc = rtr.Scene.from_bytes(G.scene(sid).to_bytes())
     fn(sc)
