@@ -558,6 +558,39 @@ def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
         assert open(out_b, "rb").read() == raw
 
 
+def test_large_flat_list(ctx, rtr):
+    """50 000 spheres as direct children of one hittable_list: the compiled traversal renders it (box tree),
+    the reference-order walk would need a 50 000-word LDS stack per lane and is refused loudly; a random
+    subset of the rays is checked against the oracle's brute-force reference-order answer."""
+    base = G.scene(23)
+    n = 50_000
+    rng = np.random.default_rng(3)
+    nodes = np.zeros(n + 1, dtype=A.NODE_DTYPE)
+    nodes["type"][0], nodes["a"][0], nodes["b"][0] = A.NODE_LIST, 0, n
+    nodes["type"][1:] = A.NODE_SPHERE
+    nodes["a"][1:] = rng.integers(0, len(base.materials), n)
+    nodes["f"][1:, 0:3] = rng.uniform(-4.0, 4.0, (n, 3))
+    nodes["f"][1:, 3] = 0.05
+    sc = rtr.Scene(0, nodes, np.arange(1, n + 1, dtype=np.int32), base.materials, base.textures, base.perlin,
+                   base.images, base.image_bytes, base.lights, base.camera, base.background)
+    ctx.upload(sc)
+    out = ctx.render(A.make_params(96, 54, 4, integrator=4, seed=2))
+    assert np.isfinite(out).all() and out.mean() > 0
+    with pytest.raises(rtr.RtrError) as e:
+        ctx.render(A.make_params(96, 54, 1, integrator=4, seed=2, flags=A.FLAG_REFERENCE_ORDER))
+    assert e.value.code == A.RTR_ERR_UNSUPPORTED
+    rays = np.zeros(256, dtype=A.HIT_DTYPE)
+    rays["o"] = rng.uniform(-6.0, 6.0, (256, 3))
+    rays["d"] = rng.normal(0.0, 1.0, (256, 3))
+    rays["t_min"], rays["t_max"], rays["rng_in"] = 0.001, np.inf, 9
+    dev = ctx.test_records("hits", rays)
+    ora = G.oracle_records(sc, "rto_hits", rays)
+    assert dev["hit"].sum() > 20 and np.array_equal(dev["hit"], ora["hit"])
+    h = ora["hit"] == 1
+    assert np.array_equal(dev["material"][h], ora["material"][h])
+    assert np.array_equal(_bits(dev["t"][h]), _bits(ora["t"][h]))
+
+
 def test_error_behaviour(ctx, rtr):
     sc = _upload(ctx, 21)
     with pytest.raises(rtr.RtrError) as e:
