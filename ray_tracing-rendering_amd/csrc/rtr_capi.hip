@@ -726,7 +726,9 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     int chunks = p->spp_chunks;
     if (chunks == 0) {
         chunks = 1;
-        while ((long long)P.n_tiles * chunks < 16384 && chunks * 2 * 32 <= p->spp && chunks < 64) chunks *= 2;
+        /* (the wavefront pool holds one slot per pixel and chunk: 4096 workgroups' worth is enough there) */
+        const long long want = pipeline == RTR_PIPELINE_WAVEFRONT ? 4096 : 16384;
+        while ((long long)P.n_tiles * chunks < want && chunks * 2 * 32 <= p->spp && chunks < 64) chunks *= 2;
     }
     P.chunks = chunks;
 
