@@ -720,15 +720,25 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     if (pipeline == RTR_PIPELINE_WAVEFRONT && p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS)
         return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs integrators 1 (RR) and 4 (MIS) only");
     const int trav = pick_trav(c, p->flags);
-    /* auto chunking: ~16 workgroups per resident slot (1024 at 4 per CU) keep the 256 CUs fed through the
-     * tail, as long as a workgroup still has >= 32 samples per pixel to amortise its start-up (measured on
-     * scenes 21 / 23 / 9: 4-8 chunks beat 1-2 by 3-10 %, 32 lose 10 %) */
+    /* auto chunking.  A workgroup renders one tile for one chunk of the samples.  More chunks = more, shorter
+     * workgroups: the 1024 resident slots (4 per CU) drain more evenly at the end of the launch, but every
+     * workgroup pays its start-up once.  Model fitted to sweeps on scenes 21 / 23 / 9 (4-8 chunks beat 1-2 by
+     * 3-10 %, 32 lose 10 %): efficiency = R / (R + 0.75) * s / (s + 2) with R = rounds over the slots and
+     * s = samples per pixel and chunk; the best power of two is taken.  It picks 8 for C2 on one GPU and 16
+     * for the 313 tiles one of 8 ranks owns (measured: 88 % of the ideal eighth, 8 chunks: 81 %). */
     int chunks = p->spp_chunks;
     if (chunks == 0) {
         chunks = 1;
-        /* (the wavefront pool holds one slot per pixel and chunk: 4096 workgroups' worth is enough there) */
-        const long long want = pipeline == RTR_PIPELINE_WAVEFRONT ? 4096 : 16384;
-        while ((long long)P.n_tiles * chunks < want && chunks * 2 * 32 <= p->spp && chunks < 64) chunks *= 2;
+        if (pipeline == RTR_PIPELINE_WAVEFRONT) { /* one pool slot per pixel and chunk: keep the pool small */
+            while ((long long)P.n_tiles * chunks < 4096 && chunks * 2 * 32 <= p->spp && chunks < 64) chunks *= 2;
+        } else {
+            double best = 0;
+            for (int cand = 1; cand <= 64 && cand <= p->spp; cand *= 2) {
+                const double rounds = (double)P.n_tiles * cand / 1024.0, s_per = (double)p->spp / cand;
+                const double eff = rounds / (rounds + 0.75) * s_per / (s_per + 2.0);
+                if (eff > best) best = eff, chunks = cand;
+            }
+        }
     }
     P.chunks = chunks;
 
