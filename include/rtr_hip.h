@@ -269,7 +269,9 @@ int rtr_upload_scene(rtr_context* ctx, const rtr_scene_desc* scene);
 /* Render the region into a DEVICE buffer of doubles, 3 per pixel:
  * d_rgb[((j - y0) * row_stride + (i - x0)) * 3 + c] = linear mean radiance
  * (sum over samples * (1/spp)); pixels of tiles this call does not own are
- * left untouched.  Asynchronous on the context stream unless `blocking`. */
+ * left untouched.  Asynchronous on the context stream unless `blocking`; further
+ * non-blocking calls queue behind it (the host waits only if the new call needs
+ * another tile list or larger buffers than the one still running). */
 int rtr_render_device(rtr_context* ctx, const rtr_render_params* params,
                       double* d_rgb, int64_t row_stride, int blocking);
 
@@ -285,7 +287,8 @@ int rtr_synchronize(rtr_context* ctx);
  * returns RTR_ERR_CANCELLED. */
 int rtr_cancel(rtr_context* ctx);
 
-/* Statistics of the last finished render call (blocks until it is finished). */
+/* Statistics of the LAST render call (blocks until it has finished).  The
+ * statistics of earlier queued calls that were never asked for are dropped. */
 int rtr_get_stats(rtr_context* ctx, rtr_render_stats* out);
 
 /* Text of the last error on this context ("" if none).  ctx may be NULL for
