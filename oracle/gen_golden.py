@@ -139,6 +139,8 @@ def write_pbr_textures(td):
 # scene ids without a dedicated fixture set above
 ALL_OTHER_SCENES = [2, 5, 6, 10, 11, 12, 13, 14, 16, 20, 25, 27, 28, 30, 31, 32, 33, 34, 36, 37, 38, 39, 40, 41, 42]
 
+PRIMITIVE_SCENES = list(range(1001, 1011))
+
 HDR_ASSETS = {24: ("brown_photostudio_02_4k.hdr", 32, 16, {(20, 4), (21, 4), (20, 5)}),
               26: ("rnl_probe.hdr", 16, 16, {(11, 5), (4, 9)})}
 
@@ -311,6 +313,17 @@ def main():
         name = "img_scene%02d_i4_32_spp4.f64" % sid
         cmd, info = run("render", sid, 4, 32, 4, 1, SCENE_SEED, os.path.join(GOLD, name), 8)
         note(name, cmd, info, scene=sid, integrator=4, width=32, height=info["height"], spp=4, seed=1)
+
+    # hit() vectors per geometry class -- scene ids 1001.. of the harness hold ONE object each
+    # (sphere, moving_sphere, xy/xz/yz_rect, box, translate(rotate_y(box)), flip_face, constant_medium over a
+    # sphere and over a transformed box), built with the reference's own constructors
+    for sid in PRIMITIVE_SCENES:
+        name = "scene%d.rtrs" % sid
+        cmd, info = run("dump-scene", sid, SCENE_SEED, os.path.join(GOLD, name))
+        note(name, cmd, info, raw_sha256=sha(os.path.join(GOLD, name)))
+        name = "hits_scene%d.bin" % sid
+        cmd, info = run("hits", sid, SCENE_SEED, 256, 900 + sid, os.path.join(GOLD, name))
+        note(name, cmd, info, scene=sid)
 
     # one mid-size image of the headline config's scene
     name = "img_scene21_i4_128_spp32.f64"

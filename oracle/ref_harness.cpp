@@ -334,10 +334,41 @@ struct Loaded {
     int default_w = 0, default_h = 0;
 };
 
+/* Scene ids >= 1001: ONE object of the reference's geometry classes as the whole world (SURVEY 8c item 2:
+ * per-primitive hit() vectors), built from the reference's own constructors. */
+static SceneConfig primitive_scene(int id) {
+    SceneConfig c;
+    auto white = make_shared<lambertian>(color(0.73, 0.73, 0.73));
+    auto smoke = color(0.2, 0.4, 0.9);
+    shared_ptr<hittable> box1 = make_shared<box>(point3(-0.8, -0.6, -0.5), point3(0.7, 0.9, 0.6), white);
+    shared_ptr<hittable> turned = make_shared<translate>(make_shared<rotate_y>(box1, 33.0), vec3(0.2, -0.1, 0.3));
+    switch (id) {
+    case 1001: c.world = make_shared<sphere>(point3(0.1, -0.2, 0.3), 1.1, white); break;
+    case 1002: c.world = make_shared<moving_sphere>(point3(-0.3, 0.0, 0.1), point3(0.4, 0.5, -0.2), 0.0, 1.0, 0.9, white); break;
+    case 1003: c.world = make_shared<xy_rect>(-1.0, 0.8, -0.7, 1.1, 0.25, white); break;
+    case 1004: c.world = make_shared<xz_rect>(-1.0, 0.8, -0.7, 1.1, -0.15, white); break;
+    case 1005: c.world = make_shared<yz_rect>(-1.0, 0.8, -0.7, 1.1, 0.35, white); break;
+    case 1006: c.world = box1; break;
+    case 1007: c.world = turned; break;
+    case 1008: c.world = make_shared<flip_face>(make_shared<xz_rect>(-1.0, 0.8, -0.7, 1.1, 0.4, white)); break;
+    case 1009: c.world = make_shared<constant_medium>(make_shared<sphere>(point3(0, 0, 0), 1.2, white), 0.9, smoke); break;
+    case 1010: c.world = make_shared<constant_medium>(turned, 1.4, smoke); break;
+    default: die("unknown primitive scene id");
+    }
+    c.aspect_ratio = 1.0;
+    c.image_width = 64;
+    c.samples_per_pixel = 4;
+    c.background = color(0.7, 0.8, 1.0);
+    c.lookfrom = point3(0.5, 0.8, -5);
+    c.lookat = point3(0, 0, 0);
+    c.vfov = 35.0;
+    return c;
+}
+
 static Loaded load_scene(int scene_id, uint32_t scene_seed) {
     Loaded l;
     set_rng(scene_seed);
-    l.cfg = select_scene(scene_id);
+    l.cfg = scene_id > 1000 ? primitive_scene(scene_id) : select_scene(scene_id);
     /* main.cpp:63-66 with RenderConfig::kShutterOpen/Close = 0/1 (main.cpp:45-46) */
     l.cam = make_shared<camera>(l.cfg.lookfrom, l.cfg.lookat, l.cfg.vup, l.cfg.vfov, l.cfg.aspect_ratio,
                                 l.cfg.aperture, l.cfg.focus_dist, 0.0, 1.0);
@@ -505,6 +536,9 @@ static int cmd_hits(int scene_id, uint32_t scene_seed, int n, uint64_t gen_seed,
         lo[c] = std::fmax(lo[c], -1200.0);
         hi[c] = std::fmin(hi[c], 1200.0);
     }
+    const vec3 box_lo = lo, box_hi = hi;
+    if (scene_id > 1000) /* one object: start rays around it, not only inside its (possibly flat) box */
+        for (int c = 0; c < 3; ++c) lo[c] -= 1.5, hi[c] += 1.5;
     for (int k = 0; k < n; ++k) {
         ray r;
         double tmin = 0.001, tmax = infinity;
@@ -516,6 +550,11 @@ static int cmd_hits(int scene_id, uint32_t scene_seed, int n, uint64_t gen_seed,
             vec3 o(lo.x() + (hi.x() - lo.x()) * U01(g), lo.y() + (hi.y() - lo.y()) * U01(g),
                    lo.z() + (hi.z() - lo.z()) * U01(g));
             vec3 d = gen_unit(g);
+            if (scene_id > 1000 && kind != 2) { /* aimed at a point of the object's box */
+                vec3 target(box_lo.x() + (box_hi.x() - box_lo.x()) * U01(g), box_lo.y() + (box_hi.y() - box_lo.y()) * U01(g),
+                            box_lo.z() + (box_hi.z() - box_lo.z()) * U01(g));
+                d = target - o;
+            }
             if (kind == 2) d = d * (0.25 + 4.0 * U01(g)); /* unnormalised directions (scatter fallbacks) */
             r = ray(o, d, U01(g));
             if (kind == 3) tmax = 50.0 + 400.0 * U01(g); /* shadow-style finite range */

@@ -385,6 +385,35 @@ def test_every_other_reference_scene(ctx, sid):
         assert G.rel_l2(out, img) <= 5e-2
 
 
+@pytest.mark.parametrize("sid", list(range(1001, 1011)))
+def test_primitive_hit_vectors(ctx, sid):
+    """SURVEY 8c item 2 on the device: one object of each geometry class as the whole world (sphere,
+    moving_sphere, the three rects, box, translate(rotate_y(box)), flip_face, constant_medium x 2), 256 rays
+    each from the reference; whatever traversal upload picks, and the reference-order walk."""
+    sc = _upload(ctx, sid)
+    gold = G.records("hits_scene%d.bin" % sid, A.HIT_DTYPE)
+    exact = sid not in (1001, 1009)  # spheres: (u,v) through acos / atan2, the medium through log()
+    for ref_order in (False, True):
+        ctx.reference_order(ref_order)
+        out = ctx.test_records("hits", gold)
+        ctx.reference_order(False)
+        assert np.array_equal(out["hit"], gold["hit"]) and np.array_equal(out["rng_out"], gold["rng_out"])
+        h = gold["hit"] == 1
+        for f in ("front_face", "material"):
+            assert np.array_equal(out[f][h], gold[f][h]), f
+        for f in ("t", "p", "n"):
+            if exact or sid == 1001:
+                assert np.array_equal(_bits(out[f][h]), _bits(gold[f][h])), f
+            else:
+                assert np.all(_close(out[f][h], gold[f][h], 1e-12)), f
+        uv = h & ~np.isnan(gold["u"])
+        for f in ("u", "v"):
+            if sid == 1001:
+                assert np.all(np.abs(out[f][uv] - gold[f][uv]) <= 1e-14), f
+            else:
+                assert np.array_equal(_bits(out[f][uv]), _bits(gold[f][uv])), f
+
+
 EVERY_SCENE = sorted(set(ALL_OTHER_SCENES) | {1, 4, 7, 8, 9, 15, 17, 18, 19, 21, 22, 23, 24, 26, 35})
 
 

@@ -168,6 +168,34 @@ def test_images(name):
     assert G.rel_l2(out, img) == 0.0
 
 
+PRIMITIVE_SCENES = {1001: "sphere", 1002: "moving_sphere", 1003: "xy_rect", 1004: "xz_rect", 1005: "yz_rect", 1006: "box",
+                    1007: "translate(rotate_y(box))", 1008: "flip_face(xz_rect)", 1009: "constant_medium(sphere)",
+                    1010: "constant_medium(translate(rotate_y(box)))"}
+
+
+@pytest.mark.parametrize("sid", sorted(PRIMITIVE_SCENES))
+def test_primitive_hit_vectors(sid):
+    """hit() of every geometry class on its own (one object = the whole world, built by the
+    reference's constructors): 256 rays each, incl. the RNG state a constant_medium leaves behind."""
+    sc = G.scene(sid)
+    gold = G.records("hits_scene%d.bin" % sid, A.HIT_DTYPE)
+    out = G.oracle_records(sc, "rto_hits", gold)
+    assert np.array_equal(out["hit"], gold["hit"]) and 0.15 < gold["hit"].mean() < 1.0
+    assert np.array_equal(out["rng_out"], gold["rng_out"])
+    h = gold["hit"] == 1
+    for f in ("front_face", "material"):
+        assert np.array_equal(out[f][h], gold[f][h]), f
+    for f in ("t", "p", "n"):
+        assert np.array_equal(_bits(out[f][h]), _bits(gold[f][h])), f
+    uv = h & ~np.isnan(gold["u"])
+    for f in ("u", "v"):
+        assert np.array_equal(_bits(out[f][uv]), _bits(gold[f][uv])), f
+    if sid in (1002, 1009, 1010):  # moving_sphere and constant_medium write no (u,v)
+        assert not uv.any()
+    if sid in (1009, 1010):
+        assert np.any(gold["rng_in"] != gold["rng_out"])
+
+
 ALL_OTHER_SCENES = [2, 5, 6, 10, 11, 12, 13, 14, 16, 20, 25, 27, 28, 30, 31, 32, 33, 34, 36, 37, 38, 39, 40, 41, 42]
 
 
