@@ -325,6 +325,15 @@ def main():
         cmd, info = run("hits", sid, SCENE_SEED, 256, 900 + sid, os.path.join(GOLD, name))
         note(name, cmd, info, scene=sid)
 
+    # material::sample / eval / pdf over a roughness x metallic grid of PBRMaterials (+ metal,
+    # dielectric, lambertian, diffuse_light): harness scene 1011
+    name = "scene1011.rtrs"
+    cmd, info = run("dump-scene", 1011, SCENE_SEED, os.path.join(GOLD, name))
+    note(name, cmd, info, raw_sha256=sha(os.path.join(GOLD, name)))
+    name = "materials_scene1011.bin"
+    cmd, info = run("materials", 1011, SCENE_SEED, 32, 4300, os.path.join(GOLD, name))
+    note(name, cmd, info, scene=1011)
+
     # one mid-size image of the headline config's scene
     name = "img_scene21_i4_128_spp32.f64"
     cmd, info = run("render", 21, 4, 128, 32, 7, SCENE_SEED, os.path.join(GOLD, name), 8)

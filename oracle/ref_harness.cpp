@@ -353,6 +353,24 @@ static SceneConfig primitive_scene(int id) {
     case 1008: c.world = make_shared<flip_face>(make_shared<xz_rect>(-1.0, 0.8, -0.7, 1.1, 0.4, white)); break;
     case 1009: c.world = make_shared<constant_medium>(make_shared<sphere>(point3(0, 0, 0), 1.2, white), 0.9, smoke); break;
     case 1010: c.world = make_shared<constant_medium>(turned, 1.4, smoke); break;
+    case 1011: { /* Cook-Torrance over a roughness x metallic grid, plus the other material classes */
+        hittable_list w;
+        const double rough[5] = {0.01, 0.05, 0.2, 0.4, 1.0}, metalness[3] = {0.0, 0.5, 1.0};
+        int k = 0;
+        for (double r : rough)
+            for (double m : metalness) {
+                auto mat = make_shared<PBRMaterial>(make_shared<solid_color>(0.9 - 0.05 * k, 0.3 + 0.04 * k, 0.2 + 0.01 * k),
+                                                    make_shared<solid_color>(r, r, r), make_shared<solid_color>(m, m, m));
+                w.add(make_shared<sphere>(point3(-3.0 + 0.45 * k, 0.0, 0.1 * k), 0.2, mat));
+                ++k;
+            }
+        w.add(make_shared<sphere>(point3(0, 1, 0), 0.3, make_shared<metal>(color(0.8, 0.6, 0.2), 0.3)));
+        w.add(make_shared<sphere>(point3(1, 1, 0), 0.3, make_shared<dielectric>(1.5)));
+        w.add(make_shared<sphere>(point3(2, 1, 0), 0.3, white));
+        w.add(make_shared<sphere>(point3(3, 1, 0), 0.3, make_shared<diffuse_light>(color(4, 4, 4))));
+        c.world = make_shared<bvh_node>(w, 0, 1);
+        break;
+    }
     default: die("unknown primitive scene id");
     }
     c.aspect_ratio = 1.0;

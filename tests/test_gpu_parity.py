@@ -79,7 +79,7 @@ def test_unit_closest_hit(ctx, sid):
     assert np.array_equal(out["front_face"][both], gold["front_face"][both])
 
 
-@pytest.mark.parametrize("sid", [23, 9, 35])
+@pytest.mark.parametrize("sid", [23, 9, 35, 1011])
 def test_unit_materials(ctx, sid):
     sc = _upload(ctx, sid)
     gold = G.records("materials_scene%02d.bin" % sid, A.MAT_DTYPE)

@@ -64,12 +64,18 @@ def test_closest_hit_vectors(sid):
         assert np.any(gold["rng_in"] != gold["rng_out"])
 
 
-@pytest.mark.parametrize("sid", [23, 9, 35])
+@pytest.mark.parametrize("sid", [23, 9, 35, 1011])
 def test_material_vectors(sid):
     """material::sample / eval / pdf / emitted (materials/material.h), textures, perlin."""
     sc = G.scene(sid)
     gold = G.records("materials_scene%02d.bin" % sid, A.MAT_DTYPE)
     out = G.oracle_records(sc, "rto_materials", gold)
+    if sid == 1011:  # the roughness x metallic grid of SURVEY 8c item 4
+        pbr = sc.materials[sc.materials["type"] == A.MAT_PBR]
+        rough = sc.textures["f"][pbr["tex"][:, 1], 0]
+        metal = sc.textures["f"][pbr["tex"][:, 2], 0]
+        assert sorted(set(rough.tolist())) == [0.01, 0.05, 0.2, 0.4, 1.0] and sorted(set(metal.tolist())) == [0.0, 0.5, 1.0]
+        assert len(pbr) == 15
     for f in ("sample_ok", "rng_out", "is_transmission"):
         assert np.array_equal(out[f], gold[f]), f
     for f in ("eval", "pdf", "emitted"):
@@ -81,7 +87,9 @@ def test_material_vectors(sid):
     for f in ("s_wi", "s_f", "s_pdf"):
         assert np.array_equal(_bits(out[f][ok]), _bits(gold[f][ok])), f
     assert np.array_equal(out["is_specular"][ok], gold["is_specular"][ok])
-    if sid == 35:  # PBRMaterial with image albedo / roughness / metallic and NORMAL maps (material.h:247-261)
+    if sid == 1011:
+        assert set(np.unique(types)) >= {A.MAT_LAMBERTIAN, A.MAT_METAL, A.MAT_DIELECTRIC, A.MAT_DIFFUSE_LIGHT, A.MAT_PBR}
+    elif sid == 35:  # PBRMaterial with image albedo / roughness / metallic and NORMAL maps (material.h:247-261)
         pbr = sc.materials[sc.materials["type"] == A.MAT_PBR]
         assert len(pbr) == 3 and np.all(pbr["tex"][:, 3] >= 0)
         assert np.all(sc.textures["type"][pbr["tex"][:, 3]] == A.TEX_IMAGE) and np.all(sc.textures["a"][pbr["tex"][:, 3]] >= 0)
