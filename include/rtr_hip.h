@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTR_ABI_VERSION 1
+#define RTR_ABI_VERSION 2 /* 2: rtr_render_stats grew spp_chunks / cancelled */
 
 /* ------------------------------------------------------------------------- */
 /* status codes                                                              */
@@ -239,6 +239,8 @@ typedef struct rtr_render_stats {
     double device_ms;          /* HIP-event time of the render kernels of the last call */
     int32_t kernel_launches;
     int32_t pipeline;          /* pipeline that actually ran                            */
+    int32_t spp_chunks;        /* partial sums per pixel that were used (params.spp_chunks, or the library's choice for 0) */
+    int32_t cancelled;         /* 1: rtr_cancel() stopped this render before its last sample */
 } rtr_render_stats;
 
 typedef struct rtr_context rtr_context;
@@ -282,9 +284,14 @@ int rtr_render_host(rtr_context* ctx, const rtr_render_params* params,
 /* Wait for everything queued on the context stream. */
 int rtr_synchronize(rtr_context* ctx);
 
-/* Thread-safe cooperative cancel (Renderer::cancel, renderer.h:113-115): the
- * running render stops at its next wavefront iteration / batch boundary and
- * returns RTR_ERR_CANCELLED. */
+/* Thread-safe cooperative cancel (Renderer::cancel, renderer.h:113-115).  Covers every render
+ * issued on the context so far, running or still queued behind another one; a render issued
+ * afterwards is not affected.  A covered render stops at its next poll (every 8th sample of a
+ * pixel / every wavefront batch) and reports RTR_ERR_CANCELLED: from the blocking call itself,
+ * otherwise as rtr_render_stats.cancelled.  Output buffer after a cancel: like the reference's
+ * workers (renderer.h:52-59), tiles whose samples all finished hold their final values and every
+ * other tile keeps what the caller's buffer held before the call (megakernel: per 16x16 tile;
+ * wavefront: no tile is written).  A cancel that arrives after the last sample has no effect. */
 int rtr_cancel(rtr_context* ctx);
 
 /* Statistics of the LAST render call (blocks until it has finished).  The

@@ -14,7 +14,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RTR_HD __host__ __device__
 #else
 #define RTR_HD

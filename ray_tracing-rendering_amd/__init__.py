@@ -24,7 +24,7 @@ def __getattr__(name):
     if name in ("Context", "RtrError", "library_path"):
         from . import native
         return getattr(native, name)
-    if name in ("Renderer", "RenderBuffer", "render_sharded", "tiles_of_rank"):
+    if name in ("Renderer", "RenderBuffer", "render_sharded", "tiles_of_rank", "gather_tiles", "pack_tiles", "unpack_tiles"):
         from . import renderer
         return getattr(renderer, name)
     raise AttributeError(name)

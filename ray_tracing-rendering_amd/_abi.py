@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-RTR_ABI_VERSION = 1
+RTR_ABI_VERSION = 2
 
 # status codes (rtr_status)
 RTR_OK = 0
@@ -86,7 +86,8 @@ class RenderParamsC(C.Structure):
 
 class RenderStatsC(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closest_segments", C.c_uint64), ("shadow_segments", C.c_uint64),
-                ("device_ms", C.c_double), ("kernel_launches", C.c_int32), ("pipeline", C.c_int32)]
+                ("device_ms", C.c_double), ("kernel_launches", C.c_int32), ("pipeline", C.c_int32),
+                ("spp_chunks", C.c_int32), ("cancelled", C.c_int32)]
 
 
 def make_params(width, height, spp, *, integrator=INTEGRATOR_MIS, seed=1, max_depth=50, rr_start_depth=3,

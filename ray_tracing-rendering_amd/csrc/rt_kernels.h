@@ -27,9 +27,15 @@ struct RenderK {
     int chunks;
     int integrator; /* RTR_INTEGRATOR_* (the wavefront's extend stage needs it for rays that miss) */
     double* partial;             /* [n_tiles*chunks][3][RTR_BLOCK] un-normalised sums */
-    unsigned long long* stats;   /* samples, closest segments, shadow segments */
-    const int* cancel;           /* set by rtr_cancel() */
+    unsigned long long* stats;   /* samples, closest segments, shadow segments; [7] = workgroups a cancel interrupted */
+    const uint32_t* cancel;      /* rtr_cancel(): id of the newest render it covers; this render stops once *cancel >= render_id */
+    uint32_t render_id;
+    int* done;                   /* [n_tiles*chunks]: 1 = the workgroup finished every sample of its chunk */
 };
+
+RT_DEV bool render_cancelled(const RenderK& P) {
+    return __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.render_id;
+}
 
 RT_DEV void tile_pixel(const RenderK& P, int slot, int tid, int& i, int& j, bool& active) {
     const int tile = P.tile_ids[slot];
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
         V3 acc = mk(0, 0, 0);
         while (!done) {
             if (fresh) { /* renderer.h:73-75 under the per-sample seed */
-                if ((s & 7) == 0 && __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if ((s & 7) == 0 && render_cancelled(P)) break;
                 rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
                 const Real u = (i + rng_next(rng)) / (P.W - 1);
                 const Real v = (j + rng_next(rng)) / (P.H - 1);
@@ -236,7 +242,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                 ++s;
                 /* rtr_cancel(): polled every 8th sample of a pixel -- the load is a dependent memory round
                  * trip in the lane's critical path */
-                done = s >= s_end || ((s & 7) == 0 && __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                done = s >= s_end || ((s & 7) == 0 && render_cancelled(P));
                 if (!done) begin_sample();
             }
         }
@@ -262,6 +268,13 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
         atomicAdd(&P.stats[1], b);
         atomicAdd(&P.stats[2], c);
     }
+    /* a cancelled render leaves unfinished tiles untouched, like the reference's workers
+     * (renderer.h:52-59): k_resolve stores a tile only when all its chunks ran to the end */
+    const int interrupted = __syncthreads_or(active && s < s_end);
+    if (threadIdx.x == 0) {
+        P.done[blockIdx.x] = !interrupted;
+        if (interrupted) atomicAdd(&P.stats[7], 1ull);
+    }
 }
 
 struct ResolveK {
@@ -276,6 +289,8 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_resolve(const ResolveK R) {
     bool active;
     tile_pixel(P, blockIdx.x, threadIdx.x, i, j, active);
     if (!active) return;
+    for (int c = 0; c < P.chunks; ++c) /* wave-uniform: scalar loads */
+        if (!P.done[blockIdx.x * P.chunks + c]) return;
     const double* in = P.partial + (size_t)blockIdx.x * P.chunks * 3 * RTR_BLOCK + threadIdx.x;
     double r = 0, g = 0, b = 0;
     for (int c = 0; c < P.chunks; ++c) {

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const Rend
         double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
         out[0] = 0, out[RTR_BLOCK] = 0, out[2 * RTR_BLOCK] = 0;
     }
+    if (threadIdx.x == 0) P.done[slot / RTR_BLOCK] = 1; /* k_resolve runs only after every slot has finished */
     const unsigned long long live = wave_sum(active ? 1ull : 0ull);
     if ((threadIdx.x & 63) == 0 && live) atomicAdd(S.n_live, (uint32_t)live);
     if (slot < 2 * WF_CNT_STRIDE) S.counters[slot] = 0;
@@ -448,7 +449,7 @@ inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
 inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool has_lights, const bool lean,
                             const bool quadlit,
                             const bool sort, const int trav, const size_t lds, const RenderK& Pin, int integrator,
-                            double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<int>* cancel,
+                            double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<uint32_t>* cancelled_upto,
                             int* launches, std::string& err) {
     RenderK P = Pin;
     const long long n_slots_ll = (long long)P.n_tiles * P.chunks * RTR_BLOCK;
@@ -552,7 +553,7 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool ha
         WF_HIP(hipMemcpyAsync(pool.h_live, S.n_live, 4, hipMemcpyDeviceToHost, stream));
         WF_HIP(hipStreamSynchronize(stream));
         if (*pool.h_live == 0) break;
-        if (cancel && cancel->load()) {
+        if (cancelled_upto && cancelled_upto->load() >= P.render_id) {
             cancelled = true;
             break;
         }

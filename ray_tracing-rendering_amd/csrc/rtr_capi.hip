@@ -51,14 +51,22 @@ struct rtr_context {
     bool uv_order_dependent = false;
     int n_material_types = 0;
     /* per-render workspace */
-    DevBuf b_tiles, b_partial, b_stats, b_cancel, b_test;
+    DevBuf b_tiles, b_partial, b_done, b_stats, b_cancel, b_test, b_stage;
     std::vector<int> last_tiles; /* what b_tiles holds */
     WavefrontPool pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stats_pending = false;
     rtr_render_stats stats{};
-    std::atomic<int> cancel_requested{0};
+    /* Cancel.  Renders are numbered; rtr_cancel() covers every render issued so far: it stores the newest
+     * id in `cancelled_upto` and in the device word the kernels poll.  A render issued afterwards carries a
+     * larger id, so nothing has to be reset between renders and a cancel that arrives while a render waits
+     * in the stream behind another one is not lost. */
+    std::atomic<uint32_t> render_seq{0};
+    std::atomic<uint32_t> cancelled_upto{0};
+    uint32_t pending_id = 0; /* id of the render whose statistics are pending */
     std::mutex cancel_mu;
+    int n_materials = 0;
+    int n_cus = 256; /* hipDeviceProp.multiProcessorCount */
 };
 
 namespace {
@@ -132,8 +140,10 @@ struct Validator {
             if (t.a >= s->n_images) return bad(RTR_ERR_INVALID, "image index out of range");
             if (t.a >= 0) {
                 const rtr_image& im = s->images[t.a];
-                if (im.width <= 0 || im.height <= 0 ||
-                    im.offset + (uint64_t)im.width * im.height * 3 > s->n_image_bytes)
+                /* width * height * 3 of two positive int32 fits a uint64; the offset is compared first so
+                 * the sum cannot wrap */
+                if (im.width <= 0 || im.height <= 0 || im.offset > s->n_image_bytes ||
+                    (uint64_t)im.width * (uint64_t)im.height * 3 > s->n_image_bytes - im.offset)
                     return bad(RTR_ERR_INVALID, "image texels out of range");
             }
             return true;
@@ -280,6 +290,21 @@ struct Validator {
                     return (bad(RTR_ERR_INVALID, "environment map texels / tables out of range or misaligned"), code);
             }
         }
+        /* every record is checked, also those the graph under `root` does not reach: upload and the
+         * scene-wide facts (material classes, texture classes) loop over whole arrays */
+        for (int k = 0; k < s->n_textures; ++k)
+            if (!texture_ok(k, 0)) return code;
+        for (int k = 0; k < s->n_materials; ++k)
+            if (!material_ok(k)) return code;
+        for (int k = 0; k < s->n_nodes; ++k) {
+            const rtr_node& n = s->nodes[k];
+            if (n.type < 0 || n.type >= RTR_NODE_TYPE_COUNT)
+                return (bad(RTR_ERR_UNSUPPORTED, "unknown hittable node type"), code);
+            if (n.type >= RTR_NODE_SPHERE && (n.a < 0 || n.a >= s->n_materials))
+                return (bad(RTR_ERR_INVALID, "material index out of range"), code);
+            if (n.type == RTR_NODE_MEDIUM && (n.b < 0 || n.b >= s->n_materials))
+                return (bad(RTR_ERR_INVALID, "material index out of range"), code);
+        }
         state.assign(s->n_nodes, 0);
         need.assign(s->n_nodes, 0);
         depth.assign(s->n_nodes, 0);
@@ -367,7 +392,8 @@ int set_lds(rtr_context* c, K kernel, size_t bytes) {
     return RTR_OK;
 }
 
-int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in) {
+/* `dry`: only what can fail without touching the stream (the LDS size check / attribute) */
+int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu = nullptr) {
     /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
     const int trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
     const int stack_words = (int)(stack_bytes(c, trav) / (RTR_BLOCK * sizeof(int)));
@@ -380,7 +406,9 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in) {
     do {                                                                                           \
         int rc_ = set_lds(c, k_mega<I, T, M>, lds);                                                \
         if (rc_) return rc_;                                                                       \
-        hipLaunchKernelGGL((k_mega<I, T, M>), grid, block, lds, c->stream, dsc, P, stack_words);   \
+        if (!dry) hipLaunchKernelGGL((k_mega<I, T, M>), grid, block, lds, c->stream, dsc, P, stack_words); \
+        if (dry && blocks_per_cu)                                                                  \
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_mega<I, T, M>, RTR_BLOCK, lds)); \
     } while (0)
 /* FULLQ = the variant for "every material, QuadLights only" (the RR integrator has no light code) */
 #define RTR_LAUNCH_T(I, FULLQ)                                              \
@@ -434,8 +462,29 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in) {
 #undef RTR_LAUNCH_N1
 #undef RTR_LAUNCH_T
 #undef RTR_LAUNCH
-    HIPCHK(c, hipGetLastError());
+    if (!dry) HIPCHK(c, hipGetLastError());
     return RTR_OK;
+}
+
+/* auto chunking.  A workgroup renders one tile for one chunk of the samples.  More chunks = more, shorter
+ * workgroups: the resident slots drain more evenly at the end of the launch, but every workgroup pays its
+ * start-up once.  Model fitted to sweeps on scenes 21 / 23 / 9 (4-8 chunks beat 1-2 by 3-10 %, 32 lose
+ * 10 %): efficiency = R / (R + 0.75) * s / (s + 2) with R = rounds over the resident slots and s = samples
+ * per pixel and chunk; the best power of two is taken.  It picks 8 for C2 on one GPU and 16 for the 313
+ * tiles one of 8 ranks owns. */
+int auto_chunks(int pipeline, double resident_slots, int n_tiles, int spp) {
+    int chunks = 1;
+    if (pipeline == RTR_PIPELINE_WAVEFRONT) { /* one pool slot per pixel and chunk: keep the pool small */
+        while ((long long)n_tiles * chunks < 4096 && chunks * 2 * 32 <= spp && chunks < 64) chunks *= 2;
+        return chunks;
+    }
+    double best = 0;
+    for (int cand = 1; cand <= 64 && cand <= spp; cand *= 2) {
+        const double rounds = (double)n_tiles * cand / resident_slots, s_per = (double)spp / cand;
+        const double eff = rounds / (rounds + 0.75) * s_per / (s_per + 2.0);
+        if (eff > best) best = eff, chunks = cand;
+    }
+    return chunks;
 }
 
 int finish_stats(rtr_context* c) {
@@ -453,6 +502,7 @@ int finish_stats(rtr_context* c) {
     c->stats.closest_segments = h[1];
     c->stats.shadow_segments = h[2];
     c->stats.device_ms = ms;
+    if (h[7]) c->stats.cancelled = 1; /* workgroups that saw the cancel before their last sample */
     c->stats_pending = false;
     return RTR_OK;
 }
@@ -514,6 +564,11 @@ int rtr_create(int device_ordinal, rtr_context** out_ctx) {
         }                                                                                    \
     } while (0)
     CREATE_CHK(hipSetDevice(device_ordinal));
+    {
+        hipDeviceProp_t prop;
+        CREATE_CHK(hipGetDeviceProperties(&prop, device_ordinal));
+        c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     CREATE_CHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     CREATE_CHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreate(&c->ev0));
@@ -521,8 +576,8 @@ int rtr_create(int device_ordinal, rtr_context** out_ctx) {
 #undef CREATE_CHK
     c->stream = c->own_stream;
     int rc = ensure(c, c->b_stats, 8 * sizeof(unsigned long long));
-    if (!rc) rc = ensure(c, c->b_cancel, sizeof(int));
-    if (!rc && hipMemset(c->b_cancel.p, 0, sizeof(int)) != hipSuccess) rc = RTR_ERR_DEVICE;
+    if (!rc) rc = ensure(c, c->b_cancel, sizeof(uint32_t));
+    if (!rc && hipMemset(c->b_cancel.p, 0, sizeof(uint32_t)) != hipSuccess) rc = RTR_ERR_DEVICE;
     if (rc) {
         g_create_error = c->err;
         rtr_destroy(c);
@@ -537,7 +592,7 @@ void rtr_destroy(rtr_context* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
-                      &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_stats, &c->b_cancel, &c->b_test,
+                      &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_done, &c->b_stats, &c->b_cancel, &c->b_test, &c->b_stage,
                       &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -661,6 +716,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.n_lights = s->n_lights;
     d.needs_uv = info.needs_uv;
     c->info = info;
+    c->n_materials = s->n_materials;
     c->lean_materials = true;
     unsigned type_mask = 0;
     for (int k = 0; k < s->n_materials; ++k) type_mask |= 1u << s->materials[k].type;
@@ -712,77 +768,74 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     P.integrator = p->integrator;
     std::vector<int> tiles = owned_tiles(*p, P.tiles_x, P.tiles_y);
     P.n_tiles = (int)tiles.size();
-    c->stats = rtr_render_stats{};
-    if (P.n_tiles == 0) return RTR_OK;
+    if (P.n_tiles == 0) { /* nothing to do: this call's statistics are all zero (an earlier render's are dropped) */
+        if ((rc = finish_stats(c))) return rc;
+        c->stats = rtr_render_stats{};
+        return RTR_OK;
+    }
 
     int pipeline = p->pipeline;
     if (pipeline == RTR_PIPELINE_AUTO) pipeline = RTR_PIPELINE_MEGAKERNEL;
     if (pipeline == RTR_PIPELINE_WAVEFRONT && p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS)
         return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs integrators 1 (RR) and 4 (MIS) only");
     const int trav = pick_trav(c, p->flags);
-    /* auto chunking.  A workgroup renders one tile for one chunk of the samples.  More chunks = more, shorter
-     * workgroups: the 1024 resident slots (4 per CU) drain more evenly at the end of the launch, but every
-     * workgroup pays its start-up once.  Model fitted to sweeps on scenes 21 / 23 / 9 (4-8 chunks beat 1-2 by
-     * 3-10 %, 32 lose 10 %): efficiency = R / (R + 0.75) * s / (s + 2) with R = rounds over the slots and
-     * s = samples per pixel and chunk; the best power of two is taken.  It picks 8 for C2 on one GPU and 16
-     * for the 313 tiles one of 8 ranks owns (measured: 88 % of the ideal eighth, 8 chunks: 81 %). */
     int chunks = p->spp_chunks;
     if (chunks == 0) {
-        chunks = 1;
-        if (pipeline == RTR_PIPELINE_WAVEFRONT) { /* one pool slot per pixel and chunk: keep the pool small */
-            while ((long long)P.n_tiles * chunks < 4096 && chunks * 2 * 32 <= p->spp && chunks < 64) chunks *= 2;
-        } else {
-            double best = 0;
-            for (int cand = 1; cand <= 64 && cand <= p->spp; cand *= 2) {
-                const double rounds = (double)P.n_tiles * cand / 1024.0, s_per = (double)p->spp / cand;
-                const double eff = rounds / (rounds + 0.75) * s_per / (s_per + 2.0);
-                if (eff > best) best = eff, chunks = cand;
-            }
-        }
+        /* workgroups of this kernel variant the chip holds at once (registers / LDS decide: 2-5 per CU) */
+        int per_cu = 4;
+        P.chunks = 1;
+        if (pipeline == RTR_PIPELINE_MEGAKERNEL && (rc = launch_mega(c, P, p->integrator, trav, true, &per_cu))) return rc;
+        chunks = auto_chunks(pipeline, (double)c->n_cus * (per_cu > 0 ? per_cu : 1), P.n_tiles, p->spp);
     }
     P.chunks = chunks;
 
-    /* a cancel that arrived before this call started is stale */
-    {
-        std::lock_guard<std::mutex> lk(c->cancel_mu);
-        c->cancel_requested.store(0);
-        HIPCHK(c, hipMemsetAsync(c->b_cancel.p, 0, sizeof(int), c->stream));
-    }
     /* A render that was queued without blocking may still be running.  Everything below is ordered behind
      * it on the stream, so the host only has to wait where it would touch memory that render still reads:
-     * another tile list, a larger partial-sum buffer, the wavefront pool.  Back-to-back renders of the same
+     * another tile list, larger workspace buffers, the wavefront pool.  Back-to-back renders of the same
      * shape (bench.py's steps) then queue up without a bubble between them; the statistics of a render nobody
      * asked for are dropped. */
     const size_t partial_bytes = (size_t)P.n_tiles * chunks * 3 * RTR_BLOCK * sizeof(double);
+    const size_t done_bytes = (size_t)P.n_tiles * chunks * sizeof(int);
     const bool same_tiles = tiles == c->last_tiles;
-    if (c->stats_pending && (!same_tiles || partial_bytes > c->b_partial.cap || pipeline == RTR_PIPELINE_WAVEFRONT)) {
+    if (c->stats_pending && (!same_tiles || partial_bytes > c->b_partial.cap || done_bytes > c->b_done.cap ||
+                             pipeline == RTR_PIPELINE_WAVEFRONT)) {
         if ((rc = finish_stats(c))) return rc;
     }
-    c->stats_pending = false;
-    c->stats = rtr_render_stats{};
+    /* everything that can fail comes before the first stream-ordered side effect, so an error return leaves
+     * a render that is still in flight (and its pending statistics) alone */
     if (!same_tiles) {
+        c->last_tiles.clear();
         if ((rc = upload(c, c->b_tiles, tiles.data(), tiles.size() * sizeof(int)))) return rc;
         c->last_tiles = tiles;
     }
+    if ((rc = ensure(c, c->b_partial, partial_bytes))) return rc;
+    if ((rc = ensure(c, c->b_done, done_bytes))) return rc;
     P.tile_ids = static_cast<const int*>(c->b_tiles.p);
     P.stats = static_cast<unsigned long long*>(c->b_stats.p);
-    P.cancel = static_cast<const int*>(c->b_cancel.p);
-    HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
-
-    if ((rc = ensure(c, c->b_partial, partial_bytes))) return rc;
+    P.cancel = static_cast<const uint32_t*>(c->b_cancel.p);
     P.partial = static_cast<double*>(c->b_partial.p);
+    P.done = static_cast<int*>(c->b_done.p);
+    if (pipeline == RTR_PIPELINE_MEGAKERNEL && (rc = launch_mega(c, P, p->integrator, trav, true))) return rc;
+
+    const uint32_t id = c->render_seq.fetch_add(1) + 1; /* rtr_cancel() from now on covers this render */
+    P.render_id = id;
+    c->stats_pending = false; /* an unfinished earlier render's statistics are dropped here */
+    c->stats = rtr_render_stats{};
+    c->stats.spp_chunks = chunks;
+    c->pending_id = id;
+    HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
         const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
         rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean, c->quad_lights_only && !c->info.needs_uv,
                               !lean && c->n_material_types > 1, trav, stack_bytes(c, trav), P, p->integrator, d_rgb,
-                              row_stride, c->stream, &c->cancel_requested, &launches, c->err);
+                              row_stride, c->stream, &c->cancelled_upto, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
-        if (rc == RTR_ERR_CANCELLED) c->cancel_requested.store(1);
+        if (rc == RTR_ERR_CANCELLED) c->stats.cancelled = 1;
         c->stats.kernel_launches = launches;
     } else {
-        if ((rc = launch_mega(c, P, p->integrator, trav))) return rc;
+        if ((rc = launch_mega(c, P, p->integrator, trav, false))) return rc;
         ResolveK R{P, d_rgb, (long long)row_stride};
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), dim3(RTR_BLOCK), 0, c->stream, R);
         HIPCHK(c, hipGetLastError());
@@ -791,10 +844,10 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->stats.pipeline = pipeline;
     c->stats_pending = true;
-    if (blocking) {
+    if (blocking || c->stats.cancelled) { /* the host-driven wavefront loop has already waited */
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if ((rc = finish_stats(c))) return rc;
-        if (c->cancel_requested.load()) return fail(c, RTR_ERR_CANCELLED, "render cancelled");
+        if (c->stats.cancelled) return fail(c, RTR_ERR_CANCELLED, "render cancelled");
     }
     return RTR_OK;
 }
@@ -806,20 +859,22 @@ int rtr_render_host(rtr_context* c, const rtr_render_params* p, double* h_rgb, i
     HIPCHK(c, hipSetDevice(c->device));
     const int w = p->x1 - p->x0, h = p->y1 - p->y0;
     const size_t bytes = (size_t)w * h * 3 * sizeof(double);
-    void* d = nullptr;
-    hipError_t e = hipMalloc(&d, bytes);
-    if (e != hipSuccess) return fail(c, RTR_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    /* pixels of tiles this call does not own keep the caller's values */
+    /* staging framebuffer kept across calls (a progressive host render calls once per band); a render
+     * still queued on the stream may be writing it */
+    if (bytes > c->b_stage.cap) HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = ensure(c, c->b_stage, bytes);
+    if (rc) return rc;
+    void* d = c->b_stage.p;
+    /* pixels of tiles this call does not own (or does not finish: cancel) keep the caller's values */
     hipError_t ce = hipMemcpy2DAsync(d, (size_t)w * 3 * sizeof(double), h_rgb, (size_t)row_stride * 3 * sizeof(double),
                                      (size_t)w * 3 * sizeof(double), h, hipMemcpyHostToDevice, c->stream);
-    int rc = ce == hipSuccess ? rtr_render_device(c, p, static_cast<double*>(d), w, 1)
-                              : fail(c, RTR_ERR_DEVICE, hipGetErrorString(ce));
+    rc = ce == hipSuccess ? rtr_render_device(c, p, static_cast<double*>(d), w, 1)
+                          : fail(c, RTR_ERR_DEVICE, hipGetErrorString(ce));
     if (rc == RTR_OK || rc == RTR_ERR_CANCELLED) {
         hipError_t e2 = hipMemcpy2D(h_rgb, (size_t)row_stride * 3 * sizeof(double), d, (size_t)w * 3 * sizeof(double),
                                     (size_t)w * 3 * sizeof(double), h, hipMemcpyDeviceToHost);
         if (e2 != hipSuccess) rc = fail(c, RTR_ERR_DEVICE, hipGetErrorString(e2));
     }
-    hipFree(d);
     return rc;
 }
 
@@ -833,10 +888,13 @@ int rtr_synchronize(rtr_context* c) {
 int rtr_cancel(rtr_context* c) {
     if (!c) return RTR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(c->cancel_mu);
-    c->cancel_requested.store(1);
-    static const int one = 1;
+    /* static: the copy may still read the word after this function has returned an error */
+    static thread_local uint32_t upto;
+    upto = c->render_seq.load();
+    if (upto == 0 || upto == c->cancelled_upto.load()) return RTR_OK; /* nothing issued since the last cancel */
+    c->cancelled_upto.store(upto);
     hipSetDevice(c->device);
-    hipError_t e = hipMemcpyAsync(c->b_cancel.p, &one, sizeof(int), hipMemcpyHostToDevice, c->side_stream);
+    hipError_t e = hipMemcpyAsync(c->b_cancel.p, &upto, sizeof(uint32_t), hipMemcpyHostToDevice, c->side_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->side_stream);
     return e == hipSuccess ? RTR_OK : RTR_ERR_DEVICE;
 }
@@ -898,7 +956,7 @@ int rtr_test_materials(rtr_context* c, rtr_mat_record* recs, int64_t n) {
     int rc = test_begin(c, recs, n, sizeof *recs);
     if (rc || n == 0) return rc;
     for (int64_t k = 0; k < n; ++k)
-        if (recs[k].material < 0 || recs[k].material >= (int)(c->b_mats.cap / sizeof(rtr_material)))
+        if (recs[k].material < 0 || recs[k].material >= c->n_materials)
             return fail(c, RTR_ERR_INVALID, "material index out of range");
     hipLaunchKernelGGL(k_test_materials, test_grid(n), dim3(RTR_BLOCK), 0, c->stream, c->ds,
                        static_cast<rtr_mat_record*>(c->b_test.p), (long long)n);

@@ -149,10 +149,14 @@ class Context:
         self._chk(self._L.rtr_render_device(self._h, C.byref(params), C.c_void_p(device_ptr), int(row_stride),
                                             1 if blocking else 0))
 
-    def render(self, params):
-        """Blocking render to a host array (H, W, 3) of the region (includes the D2H copy)."""
+    def render(self, params, out=None):
+        """Blocking render to a host array (H, W, 3) of the region (includes the D2H copy).  Pixels of
+        tiles the call does not own or, after a cancel, did not finish keep the values of ``out``."""
         h, w = params.y1 - params.y0, params.x1 - params.x0
-        out = np.zeros((h, w, 3), dtype=np.float64)
+        if out is None:
+            out = np.zeros((h, w, 3), dtype=np.float64)
+        if out.shape != (h, w, 3) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape (%d, %d, 3)" % (h, w))
         self._chk(self._L.rtr_render_host(self._h, C.byref(params), out.ctypes.data, w))
         return out
 
@@ -166,7 +170,8 @@ class Context:
         s = A.RenderStatsC()
         self._chk(self._L.rtr_get_stats(self._h, C.byref(s)))
         return {"samples": s.samples, "closest_segments": s.closest_segments, "shadow_segments": s.shadow_segments,
-                "device_ms": s.device_ms, "kernel_launches": s.kernel_launches, "pipeline": s.pipeline}
+                "device_ms": s.device_ms, "kernel_launches": s.kernel_launches, "pipeline": s.pipeline,
+                "spp_chunks": s.spp_chunks, "cancelled": bool(s.cancelled)}
 
     def reference_order(self, on):
         """Force the reference-order traversal for rtr_test_hits (renders use params.flags)."""

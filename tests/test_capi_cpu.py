@@ -36,6 +36,7 @@ def test_sample_seed_matches_oracle():
 def test_struct_sizes_match_headers():
     assert C.sizeof(A.SceneDescC) == 4 * 10 + 8 + 8 * 8 + 192 + 24
     assert C.sizeof(A.RenderParamsC) == 16 * 4
+    assert C.sizeof(A.RenderStatsC) == 3 * 8 + 8 + 4 * 4
     assert C.sizeof(rtr.native.SceneInfoC) == 12 * 4
     assert C.sizeof(A.CameraC) == 192
 
@@ -118,6 +119,45 @@ def test_validate_rejects_malformed_scenes():
     sc = G.scene(21)
     sc.root = -1
     expect(sc, A.RTR_ERR_INVALID, "root")
+
+
+def _with_extra(sc, nodes=None, materials=None, textures=None, images=None):
+    def cat(a, b):
+        return a if b is None else np.concatenate([a, b])
+    return rtr.Scene(sc.root, cat(sc.nodes, nodes), sc.list_children, cat(sc.materials, materials),
+                     cat(sc.textures, textures), sc.perlin, cat(sc.images, images), sc.image_bytes, sc.lights,
+                     sc.camera, sc.background)
+
+
+def test_validate_checks_records_the_graph_does_not_reach():
+    """rtr_upload_scene loops over whole arrays (material classes, moving_sphere materials): a record
+    no node under `root` refers to must be as well-formed as a reachable one (.rtrs files come from disk)."""
+    def expect(sc, code, frag):
+        with pytest.raises(rtr.native.RtrError) as e:
+            rtr.native.validate_scene(sc)
+        assert e.value.code == code and frag in e.value.message, e.value.message
+
+    base = G.scene(21)
+    bad_mat = np.zeros(1, dtype=A.MATERIAL_DTYPE)
+    bad_mat["type"] = 40  # 1u << 40 would be undefined behaviour in the material-class mask
+    expect(_with_extra(base, materials=bad_mat), A.RTR_ERR_UNSUPPORTED, "material type")
+    bad_mat["type"] = -3
+    expect(_with_extra(base, materials=bad_mat), A.RTR_ERR_UNSUPPORTED, "material type")
+    lam = np.zeros(1, dtype=A.MATERIAL_DTYPE)  # lambertian whose texture index is out of range
+    lam["tex"][0, 0] = 10 ** 6
+    expect(_with_extra(base, materials=lam), A.RTR_ERR_INVALID, "texture index")
+    orphan = np.zeros(1, dtype=A.NODE_DTYPE)  # moving_sphere nobody refers to, material out of range
+    orphan["type"], orphan["a"] = A.NODE_MOVING_SPHERE, 12345
+    expect(_with_extra(base, nodes=orphan), A.RTR_ERR_INVALID, "material index")
+    orphan["type"] = 99
+    expect(_with_extra(base, nodes=orphan), A.RTR_ERR_UNSUPPORTED, "node type")
+    tex = np.zeros(1, dtype=A.TEXTURE_DTYPE)
+    tex["type"], tex["a"] = A.TEX_IMAGE, 0
+    img = np.zeros(1, dtype=A.IMAGE_DTYPE)
+    img["width"], img["height"] = 2, 2
+    img["offset"] = np.uint64(2 ** 64 - 4)  # offset + 12 wraps to 8 in uint64
+    expect(_with_extra(base, textures=tex, images=img), A.RTR_ERR_INVALID, "image texels")
+    rtr.native.validate_scene(_with_extra(base, materials=np.zeros(1, dtype=A.MATERIAL_DTYPE)))  # well-formed orphan: fine
 
 
 def test_no_gpu_means_loud_failure():

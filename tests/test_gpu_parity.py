@@ -528,10 +528,11 @@ def test_cancel_from_another_thread(ctx, rtr, pipeline):
     W = H = 2048
     p = A.make_params(W, H, 256, seed=1, pipeline=pipeline, spp_chunks=1)  # ~0.4 s+ of work
     res = {}
+    buf = np.full((H, W, 3), -7.0)  # sentinel: what the caller's buffer held before the call
 
     def run():
         try:
-            ctx.render(p)
+            ctx.render(p, out=buf)
             res["rc"] = 0
         except rtr.RtrError as e:
             res["rc"] = e.code
@@ -542,8 +543,42 @@ def test_cancel_from_another_thread(ctx, rtr, pipeline):
     ctx.cancel()
     th.join(60)
     assert not th.is_alive() and res["rc"] == A.RTR_ERR_CANCELLED
+    assert ctx.stats()["cancelled"]
+    # like the reference's workers (renderer.h:52-59): a tile is either finished or untouched
+    full = ctx.render(p)
+    assert not ctx.stats()["cancelled"]
+    tiles_b = buf.reshape(H // 16, 16, W // 16, 16, 3).transpose(0, 2, 1, 3, 4).reshape(-1, 16 * 16 * 3)
+    tiles_f = full.reshape(H // 16, 16, W // 16, 16, 3).transpose(0, 2, 1, 3, 4).reshape(-1, 16 * 16 * 3)
+    untouched = np.all(tiles_b == -7.0, axis=1)
+    finished = np.all(tiles_b == tiles_f, axis=1)
+    assert np.all(untouched | finished), "%d tiles hold partial sums" % (~(untouched | finished)).sum()
+    assert untouched.any(), "the cancel came too late to test anything"
+    if pipeline == A.PIPELINE_WAVEFRONT:
+        assert untouched.all()
     again = ctx.render(A.make_params(64, 64, 2, seed=1, pipeline=pipeline))
     assert np.isfinite(again).all() and again.mean() > 0
+
+
+def test_cancel_covers_queued_renders_only(ctx, rtr):
+    """A cancel covers every render issued so far -- also one still waiting in the stream behind another --
+    and none issued afterwards."""
+    import torch
+    _upload(ctx, 21)
+    W = H = 1024
+    p = A.make_params(W, H, 256, seed=1, spp_chunks=0)
+    fb = torch.full((H, W, 3), -7.0, dtype=torch.float64, device="cuda")
+    ctx.render_into(p, fb.data_ptr(), W, blocking=False)
+    ctx.render_into(p, fb.data_ptr(), W, blocking=False)  # queued behind the first
+    ctx.cancel()
+    st = ctx.stats()  # of the second render: it must not have run to the end
+    assert st["cancelled"] and st["samples"] < W * H * 256
+    ctx.render_into(p, fb.data_ptr(), W, blocking=True)  # issued after the cancel: unaffected
+    st = ctx.stats()
+    assert not st["cancelled"] and st["samples"] == W * H * 256
+    assert float(fb.min()) >= 0.0
+    ctx.cancel()  # nothing running: must not leak into the next render
+    ctx.render_into(p, fb.data_ptr(), W, blocking=True)
+    assert not ctx.stats()["cancelled"]
 
 
 def test_large_image_shape_of_config_c5(ctx):
