@@ -4,6 +4,13 @@ import sys
 
 import pytest
 
+# torch ships its own ROCm runtime: it must be the first to load libamdhip64 in a process that also loads
+# librtr_hip.so (the same order as bench.py), or torch.cuda finds no device afterwards
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
