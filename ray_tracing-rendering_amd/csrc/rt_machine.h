@@ -55,7 +55,7 @@ struct MLane {
     BoxRay br;
     float tmin_f, tmax_f;
     int sp, node;
-    int slot; /* what the client is working on (opaque to the machine) */
+    int slot, aux; /* what the client is working on (opaque to the machine) */
 };
 
 RT_DEV bool m_any_hit(const MLane& m) { return m.best_ref >= 0 || m.best_med >= 0; }
@@ -182,11 +182,14 @@ RT_DEV void m_tree_phase(const DScene& sc, MLane& m, const Stack st, const int w
     const bool mine = m_phase(m.pos) == M_TREE;
     if (!__builtin_amdgcn_ballot_w64(mine)) return;
     const int k = m_step(m.pos), ii = m_inst(m.pos);
-    const bool first_hit_ends = ANYHIT && k >= sc.fstep_tail; /* a tree is always in a geometry step or a boundary */
-    const bool boundary = mine && as_const(sc.fstep)[mine ? k : 0].kind != 0;
+    /* a medium's step index is below fstep_tail, so `k >= fstep_tail` also says "geometry step" */
+    const bool first_hit_ends = ANYHIT && k >= sc.fstep_tail;
     int node = mine ? m.node : RT_BVH_DONE;
     int sp = m.sp;
     const int idle_before = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!mine && m_phase(m.pos) != M_IDLE));
+    /* with few lanes left at the end of a queue the limit follows their number */
+    const int busy = __builtin_popcountll(__builtin_amdgcn_ballot_w64(m_phase(m.pos) != M_IDLE));
+    const int limit = wait_limit < (busy + 2) / 3 ? wait_limit : (busy + 2) / 3;
     bool ended_early = false;
     while (true) {
         while (node >= 0) {
@@ -217,7 +220,7 @@ RT_DEV void m_tree_phase(const DScene& sc, MLane& m, const Stack st, const int w
                     m.tmax_f = float_above(t);
                     m.hit_ref = r;
                     m.hit_inst = ii;
-                    if (first_hit_ends && !boundary) ended_early = true;
+                    if (first_hit_ends) ended_early = true;
                 }
             }
             node = (sp > 0 && !ended_early) ? st.get(--sp) : RT_BVH_DONE;
@@ -225,7 +228,7 @@ RT_DEV void m_tree_phase(const DScene& sc, MLane& m, const Stack st, const int w
         const unsigned long long active = __builtin_amdgcn_ballot_w64(node != RT_BVH_DONE);
         if (!active) break;
         const int left_tree = __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && node == RT_BVH_DONE));
-        if (idle_before + left_tree >= wait_limit) break;
+        if (idle_before + left_tree >= limit) break;
     }
     if (mine) {
         m.node = node, m.sp = sp;

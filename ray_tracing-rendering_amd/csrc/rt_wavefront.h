@@ -1,40 +1,50 @@
 /*
  * rt_wavefront.h -- the wavefront pipeline: the integrator loop of
- * renderer/mis_path_integrator.h:25-150 (and rr_path_integrator.h:21-59) cut at its two
- * ray casts into stage kernels that exchange path state through SoA arrays in HBM.
+ * renderer/mis_path_integrator.h:25-150 (and the other four integrators of the reference CLI) cut at
+ * its two ray casts into stage kernels that exchange path state through SoA arrays in HBM.
  *
  * Path pool.  Slot = (owned tile, spp chunk, pixel of the tile): the same numbering as the
- * megakernel's (blockIdx, threadIdx).  A slot runs the samples of its chunk back to back
- * (in-slot regeneration), so per-pixel sums keep the sample order of renderer.h:72-79 and
- * the pool stays full until slots run out of samples.  Every array below is indexed by
- * slot, so consecutive lanes touch consecutive 8-byte words (coalesced 512 B per wave).
+ * megakernel's (blockIdx, threadIdx); 256 consecutive slots = one BLOCK = one tile's chunk.  A slot
+ * runs the samples of its chunk back to back (in-slot regeneration), so per-pixel sums keep the
+ * sample order of renderer.h:72-79 and the pool stays full until blocks run out of samples.  Every
+ * array is indexed by slot: consecutive lanes touch consecutive 8-byte words.
  *
- * One iteration (one bounce of every live path):
- *   wf_extend   flush a finished sample into the pixel sum, start the next camera sample
- *               (renderer.h:73-75), cast the closest-hit ray (mis_path_integrator.h:37),
- *               handle the miss, else store the hit and append the slot to the queue of its
- *               material type  -> material-sorted shading waves.
- *   wf_shade    over the concatenated material queues: emission + MIS weight, light sample
- *               (:72-103,191-229), BSDF sample, throughput, Russian roulette (:105-146);
- *               writes the next ray and, if the light sample is usable, a shadow request.
- *   wf_connect  slots whose shade stage left a shadow request: occlusion ray (:210-213);
- *               unoccluded -> L += contrib.
+ * One iteration (one bounce of every live path), each stage over the list of LIVE blocks only:
+ *   wf_extend   persistent threads: a wave walks its blocks, every lane takes the next slot as soon as
+ *               its previous ray is finished (the resumable traversal machine of rt_machine.h: a lane
+ *               never waits for the slowest ray of its wave).  Flush a finished sample into the
+ *               pixel sum, start the next camera sample (renderer.h:73-75), cast the closest-hit ray
+ *               (mis_path_integrator.h:37), handle the miss, else store the hit as 16 bytes:
+ *               (t, primitive reference | medium step, instance).
+ *   wf_shade    one workgroup per block; the block's hits are sorted by material class in LDS
+ *               (material-sorted shading waves), the hit record is rebuilt from (t, reference,
+ *               instance) with the reference's own arithmetic (fast_finish), then emission + MIS
+ *               weight, light sample (:72-103,191-229), BSDF sample, throughput, Russian roulette
+ *               (:105-146); writes the next ray and, if the light sample is usable, a shadow request.
+ *   wf_connect  persistent threads over the shadow requests: occlusion ray (:210-213) on the same
+ *               machine (first hit ends the cast once no medium is left to draw); unoccluded ->
+ *               L += contrib.
  * Scenes with participating media draw random numbers INSIDE both ray casts
  * (constant_medium.h:85), so there the shade stage is split around the connect stage
- * (wf_shade_a, wf_connect, wf_shade_b) to keep the reference's draw order.
+ * (phase 1, wf_connect, phase 2) to keep the reference's draw order.
  *
- * Material queues are built only when a scene mixes material classes (otherwise every wave is
- * already uniform and the shade stage walks the slots directly).  Their counters are
- * double-buffered by iteration parity: wf_extend of iteration i clears the counters of parity
- * (i+1)&1, which no kernel of iteration i touches.  Cast counts are kept per slot and summed once
- * per render: nothing in the iteration touches a shared address except one block-aggregated
- * atomic per queue.
+ * Nothing in an iteration touches a shared address: blocks belong to one wave (extend / connect) or
+ * one workgroup (shade) per launch; cast counts are summed per wave and added once per launch; the
+ * number of live slots of a block is written by the wave that walked it.  wf_compact (one
+ * workgroup) rewrites the live-block list and publishes its length to host-mapped memory; the host
+ * enqueues iterations in batches, stays at most two batches ahead of the GPU (events) and stops
+ * when a published length is zero -- it never drains the stream to look.
+ *
+ * The pipeline runs the compiled traversals (flat / box-tree / step-program scenes).  Graphs that
+ * need the reference-order walk (a medium under a transform, hollow spheres) run on the megakernel.
  */
 #pragma once
 
 #include "rt_kernels.h"
+#include "rt_machine.h"
 #include "rtr_hip_test.h"
 
+#include <algorithm>
 #include <atomic>
 #include <string>
 
@@ -56,28 +66,31 @@ struct WfState {
     uint32_t* rng;
     int32_t* samp;
     int32_t* flags;
-    /* hit record */
-    double *ht, *hpx, *hpy, *hpz, *hnx, *hny, *hnz, *hu, *hv;
-    int32_t* hmat; /* material | front_face << 30 */
-    /* shadow request */
-    double *swx, *swy, *swz, *stmax, *scx, *scy, *scz;
-    /* per-slot cast counters (summed once at the end: no per-iteration atomics) */
-    uint32_t *n_closest, *n_shadow;
-    /* material queues (only for scenes with several material classes) */
-    int32_t* q_mat;     /* [WF_NTYPES][n_slots] */
-    uint32_t* counters; /* [2][WF_NTYPES + 2]: per parity: material queue sizes */
-    uint32_t* n_live;   /* slots not yet WF_DONE */
-    int n_slots;
+    /* hit: t, reference into DScene::fprim (>= 0) or ~step of the medium that scattered the ray, instance */
+    double* ht;
+    int32_t *href, *hinst;
+    /* shadow request: origin, direction, t_max, contribution if unoccluded */
+    double *sox, *soy, *soz, *swx, *swy, *swz, *stmax, *scx, *scy, *scz;
+    /* live blocks */
+    int32_t* block_live; /* [n_blocks] slots of the block that are not WF_DONE (written by wf_extend) */
+    int32_t* list[2];    /* ping-pong lists of live blocks */
+    uint32_t* n_list;    /* [2] their lengths */
+    uint32_t* host_live; /* host-mapped: length of the newest list */
+    int n_slots, n_blocks;
 };
-#define WF_CNT_STRIDE (WF_NTYPES + 2)
 
 struct WavefrontPool {
     void* slab = nullptr;
     size_t slab_bytes = 0;
-    uint32_t* h_live = nullptr; /* pinned */
+    uint32_t* h_live = nullptr; /* pinned + mapped */
+    hipEvent_t ev[2] = {nullptr, nullptr};
     void release() {
         if (slab) (void)hipFree(slab);
         if (h_live) (void)hipHostFree(h_live);
+        for (hipEvent_t& e : ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
         slab = nullptr, slab_bytes = 0, h_live = nullptr;
     }
 };
@@ -92,30 +105,8 @@ RT_DEV void slot_pixel(const RenderK& P, int slot, int& i, int& j, int& chunk, b
     tile_pixel(P, blk / P.chunks, tid, i, j, active);
 }
 
-/* Append this block's items to global queues with ONE global atomic per queue per block:
- * lanes take a position inside the block with an LDS atomic, a leader reserves the block's
- * range, then every lane writes its slot.  (One global atomic per lane on a single counter
- * serialises at ~11 ns each on MI355X and dominated the first version of this pipeline.)
- * Must be called by all threads of the block; `q` < 0 means "nothing to append". */
-template <int NQ>
-RT_DEV void wf_block_append(uint32_t* lds_cnt /* [2*NQ] */, uint32_t* gcnt, int32_t* qbase, size_t qstride, int q,
-                            int slot) {
-    if (threadIdx.x < 2 * NQ) lds_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t pos = 0;
-    if (q >= 0) pos = atomicAdd(&lds_cnt[q], 1u);
-    __syncthreads();
-    if (threadIdx.x < NQ) {
-        const uint32_t c = lds_cnt[threadIdx.x];
-        if (c) lds_cnt[NQ + threadIdx.x] = atomicAdd(&gcnt[threadIdx.x], c);
-    }
-    __syncthreads();
-    if (q >= 0) qbase[(size_t)q * qstride + lds_cnt[NQ + q] + pos] = slot;
-}
-
 __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const RenderK P) {
     const int slot = blockIdx.x * RTR_BLOCK + threadIdx.x;
-    if (slot >= S.n_slots) return;
     int i, j, chunk;
     bool active;
     slot_pixel(P, slot, i, j, chunk, active);
@@ -125,78 +116,164 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const Rend
     S.ax[slot] = 0, S.ay[slot] = 0, S.az[slot] = 0;
     S.lx[slot] = 0, S.ly[slot] = 0, S.lz[slot] = 0;
     S.samp[slot] = s0 - 1;
-    S.n_closest[slot] = 0, S.n_shadow[slot] = 0;
     S.flags[slot] = active ? (WF_NEED_SAMPLE | WF_FIRST) : WF_DONE;
     if (!active) { /* pixels outside the region still own a partial-sum cell */
-        double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
+        double* out = P.partial + (size_t)blockIdx.x * 3 * RTR_BLOCK + threadIdx.x;
         out[0] = 0, out[RTR_BLOCK] = 0, out[2 * RTR_BLOCK] = 0;
     }
-    if (threadIdx.x == 0) P.done[slot / RTR_BLOCK] = 1; /* k_resolve runs only after every slot has finished */
-    const unsigned long long live = wave_sum(active ? 1ull : 0ull);
-    if ((threadIdx.x & 63) == 0 && live) atomicAdd(S.n_live, (uint32_t)live);
-    if (slot < 2 * WF_CNT_STRIDE) S.counters[slot] = 0;
+    const int live = __syncthreads_count(active);
+    if (threadIdx.x == 0) {
+        P.done[blockIdx.x] = 1; /* k_resolve runs only after every slot has finished */
+        S.block_live[blockIdx.x] = live;
+        S.list[0][blockIdx.x] = blockIdx.x;
+        if (blockIdx.x == 0) S.n_list[0] = (uint32_t)S.n_blocks, S.n_list[1] = 0;
+    }
 }
 
-/* once per render: fold the per-slot counters into the render statistics */
+/* once per render: finished samples per slot into the render statistics */
 __global__ void __launch_bounds__(RTR_BLOCK) wf_finish(const WfState S, const RenderK P) {
     const int slot = blockIdx.x * RTR_BLOCK + threadIdx.x;
-    unsigned long long a = 0, b = 0, c = 0;
-    if (slot < S.n_slots) {
-        int i, j, chunk;
-        bool active;
-        slot_pixel(P, slot, i, j, chunk, active);
-        const int s0 = (int)((long long)chunk * P.spp / P.chunks);
-        if (active) a = (unsigned long long)(S.samp[slot] - s0); /* samp ends at s_end: finished samples */
-        b = S.n_closest[slot], c = S.n_shadow[slot];
+    int i, j, chunk;
+    bool active;
+    slot_pixel(P, slot, i, j, chunk, active);
+    const int s0 = (int)((long long)chunk * P.spp / P.chunks);
+    unsigned long long a = 0;
+    if (active) a = (unsigned long long)(S.samp[slot] - s0); /* samp ends at s_end: finished samples */
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0 && a) atomicAdd(&P.stats[0], a);
+}
+
+/* keep the blocks that still hold live slots: list[from] -> list[from ^ 1], order preserved */
+__global__ void __launch_bounds__(1024) wf_compact(const WfState S, const int from) {
+    __shared__ uint32_t wave_total[16];
+    __shared__ uint32_t base;
+    const int32_t* in = S.list[from];
+    int32_t* out = S.list[from ^ 1];
+    const uint32_t n = S.n_list[from];
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const int b = i < n ? in[i] : -1;
+        const bool keep = b >= 0 && S.block_live[b] > 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) wave_total[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t off = base;
+        for (int w = 0; w < wave; ++w) off += wave_total[w];
+        if (keep) out[off + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < 16; ++w) t += wave_total[w];
+            base += t;
+        }
+        __syncthreads();
     }
-    a = wave_sum(a), b = wave_sum(b), c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(&P.stats[0], a);
-        if (b) atomicAdd(&P.stats[1], b);
-        if (c) atomicAdd(&P.stats[2], c);
+    if (threadIdx.x == 0) {
+        S.n_list[from ^ 1] = base;
+        __hip_atomic_store(S.host_live, base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-/* RICH = false: scenes lit by QuadLights only whose textures read no (u,v) (rtr_upload_scene
- * decides): no environment-light code on the miss branch, no (u,v) reconstruction */
-template <int TRAV, bool SORT, bool RICH>
-__global__ void __launch_bounds__(RTR_BLOCK, 4) wf_extend(const DScene* __restrict__ scp, const WfState S,
-                                                          const RenderK P, const int parity) {
-    extern __shared__ int lds_stack[];
-    const DScene& sc = *scp;
-    const Stack st{lds_stack + threadIdx.x};
-    if (SORT && blockIdx.x == 0 && threadIdx.x < WF_CNT_STRIDE)
-        S.counters[(parity ^ 1) * WF_CNT_STRIDE + threadIdx.x] = 0;
-    uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
-    unsigned n_done = 0;
-    __shared__ uint32_t lds_cnt[2 * WF_NTYPES];
-    for (int base = blockIdx.x * RTR_BLOCK; base < S.n_slots; base += gridDim.x * RTR_BLOCK) {
-        const int slot = base + threadIdx.x;
-        int qtype = -1;
-        do {
-            if (slot >= S.n_slots) break;
-            int flags = S.flags[slot];
-            const int status = WF_STATUS(flags);
-            if (status == WF_DONE) break;
-            V3 ro, rd;
-            Real tm;
-            uint32_t rng;
-            if (status == WF_NEED_SAMPLE) {
-                int i, j, chunk;
-                bool active;
-                slot_pixel(P, slot, i, j, chunk, active);
-                V3 acc = ldv(S.ax, S.ay, S.az, slot);
-                if (!(flags & WF_FIRST)) acc = add(acc, ldv(S.lx, S.ly, S.lz, slot)); /* renderer.h:77-78 */
-                const int s = S.samp[slot] + 1;
-                S.samp[slot] = s;
-                const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
-                if (s >= s_end) {
-                    S.flags[slot] = WF_DONE;
-                    double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
-                    out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
-                    ++n_done;
-                    break;
-                }
+/* ---- persistent-threads block cursor of one wave (lives in LDS: updated under divergent control flow) ---- */
+struct WaveCursor {
+    int cur, end;  /* slots [cur, end) of the current block are not handed out yet */
+    int entry;     /* next list entry of this wave */
+    int blk, done; /* current block and how many of its slots were found / became WF_DONE */
+};
+RT_DEV int lane_rank(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+struct BlockWalk {
+    volatile WaveCursor* wc;
+    const int32_t* list;
+    int n_entries, stride;
+    int32_t* block_live; /* nullptr: this stage does not count */
+    /* Hand the next slots of this wave's blocks to the calling lanes (all lanes of the wave that are in
+     * M_FETCH).  Returns the slot or -1 ("ask again"); `exhausted` = no block is left for this wave. */
+    RT_DEV int take(bool& exhausted) const {
+        exhausted = false;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(true);
+        const int n = __builtin_popcountll(mask), rank = lane_rank(mask);
+        int cur = wc->cur, end = wc->end;
+        if (cur >= end) {
+            const int entry = wc->entry, blk = wc->blk, done = wc->done;
+            if (block_live && blk >= 0 && rank == 0) block_live[blk] = RTR_BLOCK - done;
+            if (entry >= n_entries) {
+                if (rank == 0) wc->blk = -1;
+                exhausted = true;
+                return -1;
+            }
+            const int nb = list[entry];
+            cur = nb * RTR_BLOCK, end = cur + RTR_BLOCK;
+            if (rank == 0) wc->entry = entry + stride, wc->blk = nb, wc->done = 0, wc->end = end;
+        }
+        const int avail = end - cur, take_n = n < avail ? n : avail;
+        if (rank == 0) wc->cur = cur + take_n;
+        return rank < take_n ? cur + rank : -1;
+    }
+    RT_DEV void count_done(bool dead) const {
+        const unsigned long long d = __builtin_amdgcn_ballot_w64(dead);
+        if (d && lane_rank(__builtin_amdgcn_ballot_w64(true)) == 0) wc->done = wc->done + __builtin_popcountll(d);
+    }
+};
+RT_DEV BlockWalk block_walk(WaveCursor* cursors, const WfState& S, int parity, bool count) {
+    const int wave = threadIdx.x >> 6, waves_per_block = RTR_BLOCK / 64;
+    BlockWalk w;
+    w.wc = cursors + wave;
+    w.list = S.list[parity];
+    w.n_entries = (int)S.n_list[parity];
+    w.stride = gridDim.x * waves_per_block;
+    w.block_live = count ? S.block_live : nullptr;
+    if ((threadIdx.x & 63) == 0) {
+        cursors[wave].cur = 0, cursors[wave].end = 0;
+        cursors[wave].entry = blockIdx.x * waves_per_block + wave;
+        cursors[wave].blk = -1, cursors[wave].done = 0;
+    }
+    return w;
+}
+
+/* ---- extend ------------------------------------------------------------------------------------------ */
+/* RICH = false: scenes lit by QuadLights only: no environment-light code on the miss branch */
+template <bool RICH>
+struct ExtendClient {
+    const DScene& sc;
+    const WfState& S;
+    const RenderK& P;
+    BlockWalk walk;
+    unsigned n_closest;
+
+    RT_DEV void fetch(MLane& m) {
+        bool exhausted;
+        const int slot = walk.take(exhausted);
+        if (exhausted) {
+            m.pos = M_IDLE;
+            return;
+        }
+        if (slot < 0) return;
+        int flags = S.flags[slot];
+        const int status = WF_STATUS(flags);
+        bool dead = status == WF_DONE;
+        V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
+        Real tm = 0;
+        uint32_t rng = 1;
+        if (status == WF_NEED_SAMPLE) {
+            int i, j, chunk;
+            bool active;
+            slot_pixel(P, slot, i, j, chunk, active);
+            V3 acc = ldv(S.ax, S.ay, S.az, slot);
+            if (!(flags & WF_FIRST)) acc = add(acc, ldv(S.lx, S.ly, S.lz, slot)); /* renderer.h:77-78 */
+            const int s = S.samp[slot] + 1;
+            S.samp[slot] = s;
+            const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+            if (s >= s_end) {
+                S.flags[slot] = WF_DONE;
+                double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
+                out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
+                dead = true;
+            } else {
                 stv(S.ax, S.ay, S.az, slot, acc);
                 rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
                 const Real u = (i + rng_next(rng)) / (P.W - 1);
@@ -209,79 +286,135 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4) wf_extend(const DScene* __restri
                 stv(S.lx, S.ly, S.lz, slot, mk(0.0, 0.0, 0.0));
                 S.pdf[slot] = 0.0;
                 flags = 0; /* depth 0, not specular */
-            } else {
-                ro = ldv(S.ox, S.oy, S.oz, slot);
-                rd = ldv(S.dx, S.dy, S.dz, slot);
-                tm = S.tm[slot];
-                rng = S.rng[slot];
-                flags &= ~3;
             }
-            Hit rec;
-            rec.u = 0, rec.v = 0;
-            S.n_closest[slot] += 1;
-            if (!cast_closest<TRAV, RICH>(sc, ro, rd, tm, rec, rng, st)) {
-                /* mis_path_integrator.h:37-67, rr_path_integrator.h:31-33 */
-                const V3 thr = ldv(S.tx, S.ty, S.tz, slot);
-                V3 add_l;
-                if (P.integrator == RTR_INTEGRATOR_MIS)
-                    add_l = miss_radiance<RTR_INTEGRATOR_MIS, RICH ? RT_MS_FULL : RT_MS_QUADLIT>(sc, thr, ro, rd, flags >> 8, (flags & WF_SPEC) != 0,
-                                                              S.pdf[slot]);
-                else
-                    add_l = mul(thr, ld3(sc.background));
-                stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), add_l));
-                S.flags[slot] = flags | WF_NEED_SAMPLE;
-                S.rng[slot] = rng;
-                break;
-            }
-            S.ht[slot] = rec.t;
-            stv(S.hpx, S.hpy, S.hpz, slot, rec.p);
-            stv(S.hnx, S.hny, S.hnz, slot, rec.n);
-            if (sc.needs_uv) S.hu[slot] = rec.u, S.hv[slot] = rec.v;
-            S.hmat[slot] = rec.mat | (rec.front ? (1 << 30) : 0);
+        } else if (!dead) {
+            ro = ldv(S.ox, S.oy, S.oz, slot);
+            rd = ldv(S.dx, S.dy, S.dz, slot);
+            tm = S.tm[slot];
+            rng = S.rng[slot];
+            flags &= ~3;
+        }
+        walk.count_done(dead);
+        if (dead) return; /* ask for another slot */
+        m.slot = slot;
+        m.aux = flags;
+        ++n_closest;
+        m_begin(m, ro, rd, tm, RT_INF, rng);
+    }
+
+    RT_DEV void finish(MLane& m) {
+        const int slot = m.slot, flags = m.aux;
+        if (!m_any_hit(m)) { /* mis_path_integrator.h:37-67, rr_path_integrator.h:31-33 */
+            const V3 thr = ldv(S.tx, S.ty, S.tz, slot);
+            V3 add_l;
+            if (RICH && P.integrator == RTR_INTEGRATOR_MIS)
+                add_l = miss_radiance<RTR_INTEGRATOR_MIS, RT_MS_FULL>(sc, thr, m.o, m.d, flags >> 8, (flags & WF_SPEC) != 0,
+                                                                      S.pdf[slot]);
+            else if (RICH && P.integrator == RTR_INTEGRATOR_NEE)
+                add_l = miss_radiance<RTR_INTEGRATOR_NEE, RT_MS_FULL>(sc, thr, m.o, m.d, flags >> 8, (flags & WF_SPEC) != 0, 0.0);
+            else
+                add_l = mul(thr, ld3(sc.background));
+            stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), add_l));
+            S.flags[slot] = flags | WF_NEED_SAMPLE;
+        } else {
+            S.ht[slot] = m.best_t;
+            S.href[slot] = m.best_med >= 0 ? ~m.best_med : m.best_ref;
+            S.hinst[slot] = m.best_inst;
             S.flags[slot] = flags | WF_HIT;
-            S.rng[slot] = rng;
-            if (SORT) qtype = as_const(sc.materials)[rec.mat].type;
-        } while (false);
-        if (SORT) wf_block_append<WF_NTYPES>(lds_cnt, cnt, S.q_mat, (size_t)S.n_slots, qtype, slot);
+        }
+        S.rng[slot] = m.rng;
+        m.pos = M_FETCH;
     }
-    const unsigned long long d = wave_sum(n_done);
-    if ((threadIdx.x & 63) == 0 && d) atomicSub(S.n_live, (uint32_t)d);
+};
+
+#ifndef RTR_WF_EXTEND_WAVES
+#define RTR_WF_EXTEND_WAVES 4
+#endif
+
+template <bool RICH>
+__global__ void __launch_bounds__(RTR_BLOCK, RTR_WF_EXTEND_WAVES)
+    wf_extend(const DScene* __restrict__ scp, const WfState S, const RenderK P, const int parity) {
+    extern __shared__ int lds_stack[];
+    __shared__ WaveCursor cursors[RTR_BLOCK / 64];
+    const DScene& sc = *scp;
+    const Stack st{lds_stack + threadIdx.x};
+    ExtendClient<RICH> client{sc, S, P, block_walk(cursors, S, parity, true), 0u};
+    MLane m;
+    m.pos = M_FETCH;
+    m_run<false>(sc, m, st, client);
+    const unsigned long long c = wave_sum(client.n_closest);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[1], c);
 }
 
-/* k-th entry of the concatenated material queues */
-RT_DEV int wf_sorted_slot(const WfState& S, const uint32_t* cnt, uint32_t k) {
-#pragma unroll
-    for (int t = 0; t < WF_NTYPES; ++t) {
-        const uint32_t c = cnt[t];
-        if (k < c) return S.q_mat[(size_t)t * S.n_slots + k];
-        k -= c;
+/* ---- connect: occlusion rays of the pending light connections (mis_path_integrator.h:210-213) ------------ */
+template <bool MEDIA>
+struct ConnectClient {
+    const DScene& sc;
+    const WfState& S;
+    BlockWalk walk;
+    unsigned n_shadow;
+
+    RT_DEV void fetch(MLane& m) {
+        bool exhausted;
+        const int slot = walk.take(exhausted);
+        if (exhausted) {
+            m.pos = M_IDLE;
+            return;
+        }
+        if (slot < 0) return;
+        const int flags = S.flags[slot];
+        if (!(flags & WF_SHADOW)) return;
+        S.flags[slot] = flags & ~WF_SHADOW;
+        m.slot = slot;
+        ++n_shadow;
+        /* shadow_ray = ray(rec.p, wi, time 0) over [0.001, dist - 0.001] (:210-213) */
+        m_begin(m, ldv(S.sox, S.soy, S.soz, slot), ldv(S.swx, S.swy, S.swz, slot), 0.0, S.stmax[slot],
+                MEDIA ? S.rng[slot] : 1u);
     }
-    return -1;
+    RT_DEV void finish(MLane& m) {
+        const int slot = m.slot;
+        if (MEDIA) S.rng[slot] = m.rng;
+        if (!m_any_hit(m)) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
+        m.pos = M_FETCH;
+    }
+};
+
+template <bool MEDIA>
+__global__ void __launch_bounds__(RTR_BLOCK, RTR_WF_EXTEND_WAVES)
+    wf_connect(const DScene* __restrict__ scp, const WfState S, const RenderK P, const int parity) {
+    extern __shared__ int lds_stack[];
+    __shared__ WaveCursor cursors[RTR_BLOCK / 64];
+    const DScene& sc = *scp;
+    const Stack st{lds_stack + threadIdx.x};
+    ConnectClient<MEDIA> client{sc, S, block_walk(cursors, S, parity, false), 0u};
+    MLane m;
+    m.pos = M_FETCH;
+    m_run<true>(sc, m, st, client);
+    const unsigned long long c = wave_sum(client.n_shadow);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[2], c);
 }
 
-RT_DEV void wf_load_hit(const DScene& sc, const WfState& S, int slot, Hit& rec) {
-    rec.t = S.ht[slot];
-    rec.p = ldv(S.hpx, S.hpy, S.hpz, slot);
-    rec.n = ldv(S.hnx, S.hny, S.hnz, slot);
+/* ---- shade ----------------------------------------------------------------------------------------------- */
+/* the hit record of the reference, rebuilt from what wf_extend stored */
+template <bool UV_POSSIBLE>
+RT_DEV void wf_hit_record(const DScene& sc, const WfState& S, int slot, V3 o, V3 d, Real tm, Hit& rec) {
+    const Real t = S.ht[slot];
+    const int ref = S.href[slot];
     rec.u = 0, rec.v = 0;
-    if (sc.needs_uv) rec.u = S.hu[slot], rec.v = S.hv[slot];
-    const int m = S.hmat[slot];
-    rec.mat = m & ~(1 << 30);
-    rec.front = (m >> 30) & 1;
+    if (ref < 0) { /* constant_medium.h:95-101 */
+        rec.t = t;
+        rec.p = add(o, scl(t, d));
+        rec.n = mk(1, 0, 0);
+        rec.front = true;
+        rec.mat = as_const(sc.fstep)[~ref].mat;
+    } else if (UV_POSSIBLE && sc.needs_uv) {
+        fast_finish<true>(sc, o, d, tm, t, ref, S.hinst[slot], rec);
+    } else {
+        fast_finish<false>(sc, o, d, tm, t, ref, S.hinst[slot], rec);
+    }
 }
 
-RT_DEV void wf_load_path(const WfState& S, int slot, int flags, PathState& ps) {
-    ps.ro = ldv(S.ox, S.oy, S.oz, slot);
-    ps.rd = ldv(S.dx, S.dy, S.dz, slot);
-    ps.tm = S.tm[slot];
-    ps.thr = ldv(S.tx, S.ty, S.tz, slot);
-    ps.L = ldv(S.lx, S.ly, S.lz, slot);
-    ps.prev_bsdf_pdf = S.pdf[slot];
-    ps.depth = flags >> 8;
-    ps.specular_bounce = (flags & WF_SPEC) != 0;
-}
-
-/* after shade_b / shade_rr: store the continued path or mark the sample finished */
+/* after the second half of a bounce: store the continued path or mark the sample finished */
 RT_DEV void wf_store_path(const WfState& S, int slot, const PathState& ps, bool go, int max_depth, int extra_flags) {
     int depth = ps.depth;
     if (go) {
@@ -295,89 +428,97 @@ RT_DEV void wf_store_path(const WfState& S, int slot, const PathState& ps, bool 
         (go ? WF_CONTINUE : WF_NEED_SAMPLE) | (ps.specular_bounce ? WF_SPEC : 0) | (depth << 8) | extra_flags;
 }
 
-RT_DEV void wf_store_shadow(const WfState& S, int slot, const ShadowReq& rq) {
-    stv(S.swx, S.swy, S.swz, slot, rq.wi);
-    S.stmax[slot] = rq.tmax;
-    stv(S.scx, S.scy, S.scz, slot, rq.contrib);
-}
-
 /* PHASE 0: whole shading (no media).  PHASE 1: first half only (emission + light sample).
  * PHASE 2: second half only (BSDF sample + roulette), after the connect stage.
- * SORT: walk the material-sorted queues; otherwise walk the slots and take those that hit. */
+ * SORT: the block's hits are shaded in material-class order (scenes that mix classes). */
 template <int INTEG, int PHASE, int MS, bool SORT>
-__global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? 4 : 2) wf_shade(const DScene* __restrict__ scp,
-                                                                                const WfState S, const RenderK P,
-                                                                                const int parity) {
+__global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? 4 : 2)
+    wf_shade(const DScene* __restrict__ scp, const WfState S, const RenderK P, const int parity) {
     const DScene& sc = *scp;
-    const uint32_t* cnt = S.counters + parity * WF_CNT_STRIDE;
-    uint32_t total = (uint32_t)S.n_slots;
-    if (SORT) {
-        total = 0;
-#pragma unroll
-        for (int t = 0; t < WF_NTYPES; ++t) total += cnt[t];
-    }
-    for (uint32_t k = blockIdx.x * RTR_BLOCK + threadIdx.x; k < total; k += gridDim.x * RTR_BLOCK) {
-        const int slot = SORT ? wf_sorted_slot(S, cnt, k) : (int)k;
-        const int flags = S.flags[slot];
-        if (!SORT && WF_STATUS(flags) != WF_HIT) continue;
-        Hit rec;
-        wf_load_hit(sc, S, slot, rec);
+    const int32_t* list = S.list[parity];
+    const int n_entries = (int)S.n_list[parity];
+    __shared__ int key_count[WF_NTYPES];
+    __shared__ short order[RTR_BLOCK];
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const int slot0 = list[e] * RTR_BLOCK;
+        int slot = slot0 + threadIdx.x;
+        int flags = S.flags[slot];
+        bool work = WF_STATUS(flags) == WF_HIT;
+        if (SORT) { /* counting sort of the block's hits by material class */
+            if (threadIdx.x < WF_NTYPES) key_count[threadIdx.x] = 0;
+            __syncthreads();
+            int key = -1, pos = 0;
+            if (work) {
+                const int ref = S.href[slot];
+                const int mat = ref < 0 ? as_const(sc.fstep)[~ref].mat : as_const(sc.fprim)[ref].a;
+                key = as_const(sc.materials)[mat].type;
+                pos = atomicAdd(&key_count[key], 1);
+            }
+            __syncthreads();
+            int total = 0;
+            for (int q = 0; q < WF_NTYPES; ++q) {
+                const int c = key_count[q];
+                if (q < key) pos += c;
+                total += c;
+            }
+            if (work) order[pos] = (short)threadIdx.x;
+            __syncthreads();
+            work = (int)threadIdx.x < total;
+            if (work) {
+                slot = slot0 + order[threadIdx.x];
+                flags = S.flags[slot];
+            }
+            __syncthreads(); /* order[] is rewritten by the next block of this workgroup */
+        }
+        if (!work) continue;
         PathState ps;
-        wf_load_path(S, slot, flags, ps);
+        ps.ro = ldv(S.ox, S.oy, S.oz, slot);
+        ps.rd = ldv(S.dx, S.dy, S.dz, slot);
+        ps.tm = S.tm[slot];
+        ps.thr = ldv(S.tx, S.ty, S.tz, slot);
+        ps.L = mk(0.0, 0.0, 0.0); /* at most one term (the emission) is added here: L + e is the rounding of L += e */
+        ps.prev_bsdf_pdf = S.pdf[slot];
+        ps.depth = flags >> 8;
+        ps.specular_bounce = (flags & WF_SPEC) != 0;
+        Hit rec;
+        wf_hit_record<MS == RT_MS_FULL>(sc, S, slot, ps.ro, ps.rd, ps.tm, rec);
         uint32_t rng = S.rng[slot];
         bool go;
         int extra = flags & WF_SHADOW; /* phase 2 keeps what phase 1 requested */
-        if (INTEG == RTR_INTEGRATOR_MIS) {
+        if (INTEG == RTR_INTEGRATOR_RR) {
+            go = shade_rr<MS>(sc, ps, rec, rng, P.rr_start);
+            extra = 0;
+        } else if (INTEG == RTR_INTEGRATOR_PATH) {
+            go = shade_path<MS>(sc, ps, rec, rng);
+            extra = 0;
+        } else {
             const V3 wo = neg(unit(ps.rd));
             const MatCtx mc = mat_prepare<MS>(sc, rec);
             if (PHASE != 2) {
-                const V3 L0 = ps.L;
                 ShadowReq rq;
-                shade_a_mis<MS>(sc, ps, rec, mc, wo, rng, rq);
-                if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
+                shade_a_mis<MS, INTEG>(sc, ps, rec, mc, wo, rng, rq);
                 extra = 0;
                 if (rq.valid) {
-                    wf_store_shadow(S, slot, rq);
+                    stv(S.sox, S.soy, S.soz, slot, rec.p);
+                    stv(S.swx, S.swy, S.swz, slot, rq.wi);
+                    S.stmax[slot] = rq.tmax;
+                    stv(S.scx, S.scy, S.scz, slot, rq.contrib);
                     extra = WF_SHADOW;
                 }
             }
             if (PHASE == 1) {
+                if (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)
+                    stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ps.L));
                 S.rng[slot] = rng;
                 if (extra) S.flags[slot] = flags | WF_SHADOW;
                 continue;
             }
-            go = shade_b_mis<MS>(sc, ps, rec, mc, wo, rng, P.rr_start);
-        } else {
-            const V3 L0 = ps.L;
-            go = shade_rr<MS>(sc, ps, rec, rng, P.rr_start);
-            if (ps.L.x != L0.x || ps.L.y != L0.y || ps.L.z != L0.z) stv(S.lx, S.ly, S.lz, slot, ps.L);
-            extra = 0;
+            go = shade_b_mis<MS, INTEG>(sc, ps, rec, mc, wo, rng, P.rr_start);
         }
+        if (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)
+            stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ps.L));
         wf_store_path(S, slot, ps, go, P.max_depth, PHASE == 2 ? 0 : extra);
         S.rng[slot] = rng;
-    }
-}
-
-/* occlusion rays of the pending light connections (mis_path_integrator.h:210-213) */
-template <int TRAV>
-__global__ void __launch_bounds__(RTR_BLOCK, 4) wf_connect(const DScene* __restrict__ scp, const WfState S,
-                                                           const RenderK P) {
-    extern __shared__ int lds_stack[];
-    const DScene& sc = *scp;
-    const Stack st{lds_stack + threadIdx.x};
-    for (int slot = blockIdx.x * RTR_BLOCK + threadIdx.x; slot < S.n_slots; slot += gridDim.x * RTR_BLOCK) {
-        const int flags = S.flags[slot];
-        if (!(flags & WF_SHADOW)) continue;
-        S.flags[slot] = flags & ~WF_SHADOW;
-        /* shadow_ray origin = rec.p (:210); the hit record outlives the shade stage */
-        const V3 o = ldv(S.hpx, S.hpy, S.hpz, slot);
-        const V3 wi = ldv(S.swx, S.swy, S.swz, slot);
-        const bool MEDIA = TRAV == RT_TRAV_MEDIA || TRAV == RT_TRAV_PROGRAM;
-        uint32_t rng = MEDIA ? S.rng[slot] : 1u;
-        S.n_shadow[slot] += 1;
-        const bool hit = cast_shadow<TRAV>(sc, o, wi, S.stmax[slot], rng, st);
-        if (MEDIA) S.rng[slot] = rng;
-        if (!hit) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
     }
 }
 
@@ -392,11 +533,10 @@ inline int wf_fail(std::string& err, int code, const std::string& m) {
         if (e_ != hipSuccess) return wf_fail(err, RTR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, bool sort, std::string& err) {
-    const size_t n = (size_t)n_slots;
-    const size_t n_f64 = 33; /* ray 7, path 10, hit 9, shadow 7 */
-    const size_t bytes = n_f64 * n * 8 + 6 * n * 4 /* rng samp flags hmat n_closest n_shadow */ +
-                         (sort ? (size_t)WF_NTYPES * n * 4 : 0) + (2 * WF_CNT_STRIDE + 2) * 4 + 256;
+inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, std::string& err) {
+    const size_t n = (size_t)n_slots, nb = n / RTR_BLOCK;
+    const size_t n_f64 = 28; /* ray 7, path 10, hit t 1, shadow 10 */
+    const size_t bytes = n_f64 * n * 8 + 5 * n * 4 /* rng samp flags href hinst */ + 3 * nb * 4 + 256;
     if (pool.slab_bytes < bytes) {
         if (pool.slab) WF_HIP(hipFree(pool.slab));
         pool.slab = nullptr, pool.slab_bytes = 0;
@@ -404,7 +544,10 @@ inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, bool sort, std
         if (e != hipSuccess) return wf_fail(err, RTR_ERR_NOMEM, std::string("hipMalloc(path pool): ") + hipGetErrorString(e));
         pool.slab_bytes = bytes;
     }
-    if (!pool.h_live) WF_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.h_live), 64, hipHostMallocDefault));
+    if (!pool.h_live) {
+        WF_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.h_live), 64, hipHostMallocMapped));
+        for (hipEvent_t& e : pool.ev) WF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     char* p = static_cast<char*>(pool.slab);
     auto f64 = [&]() {
         double* r = reinterpret_cast<double*>(p);
@@ -412,9 +555,9 @@ inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, bool sort, std
         return r;
     };
     double** arrs[] = {&S.ox, &S.oy, &S.oz, &S.dx, &S.dy, &S.dz, &S.tm, &S.tx, &S.ty, &S.tz, &S.lx,
-                       &S.ly, &S.lz, &S.ax, &S.ay, &S.az, &S.pdf, &S.ht, &S.hpx, &S.hpy, &S.hpz, &S.hnx,
-                       &S.hny, &S.hnz, &S.hu, &S.hv, &S.swx, &S.swy, &S.swz, &S.stmax, &S.scx, &S.scy, &S.scz};
-    static_assert(sizeof(arrs) / sizeof(arrs[0]) == 33, "array count");
+                       &S.ly, &S.lz, &S.ax, &S.ay, &S.az, &S.pdf, &S.ht, &S.sox, &S.soy, &S.soz, &S.swx,
+                       &S.swy, &S.swz, &S.stmax, &S.scx, &S.scy, &S.scz};
+    static_assert(sizeof(arrs) / sizeof(arrs[0]) == 28, "array count");
     for (double** a : arrs) *a = f64();
     auto i32 = [&](size_t count) {
         int32_t* r = reinterpret_cast<int32_t*>(p);
@@ -424,13 +567,17 @@ inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, bool sort, std
     S.rng = reinterpret_cast<uint32_t*>(i32(n));
     S.samp = i32(n);
     S.flags = i32(n);
-    S.hmat = i32(n);
-    S.n_closest = reinterpret_cast<uint32_t*>(i32(n));
-    S.n_shadow = reinterpret_cast<uint32_t*>(i32(n));
-    S.q_mat = sort ? i32((size_t)WF_NTYPES * n) : nullptr;
-    S.counters = reinterpret_cast<uint32_t*>(i32(2 * WF_CNT_STRIDE));
-    S.n_live = reinterpret_cast<uint32_t*>(i32(2));
+    S.href = i32(n);
+    S.hinst = i32(n);
+    S.block_live = i32(nb);
+    S.list[0] = i32(nb);
+    S.list[1] = i32(nb);
+    S.n_list = reinterpret_cast<uint32_t*>(i32(2));
+    void* dev_live = nullptr;
+    WF_HIP(hipHostGetDevicePointer(&dev_live, pool.h_live, 0));
+    S.host_live = static_cast<uint32_t*>(dev_live);
     S.n_slots = n_slots;
+    S.n_blocks = (int)nb;
     return RTR_OK;
 }
 
@@ -444,130 +591,114 @@ inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
     return RTR_OK;
 }
 
-/* Runs the whole render on `stream` and returns when it has finished (the iteration loop is
- * driven from the host, which polls the live-slot counter every `check` iterations). */
-inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const bool has_lights, const bool lean,
-                            const bool quadlit,
-                            const bool sort, const int trav, const size_t lds, const RenderK& Pin, int integrator,
-                            double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<uint32_t>* cancelled_upto,
-                            int* launches, std::string& err) {
+struct WavefrontPlan {
+    bool has_lights, lean, quadlit, sort, media;
+    int n_cus;
+    size_t lds; /* traversal stack of the extend / connect stages */
+};
+
+/* Enqueues the whole render on `stream`.  The host stays at most two batches of iterations ahead of
+ * the GPU and returns once the published number of live blocks is zero (everything it enqueued past that
+ * point finds empty lists); it does not wait for the stream to drain. */
+inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan& plan, const RenderK& Pin,
+                            int integrator, double* d_rgb, int64_t row_stride, hipStream_t stream,
+                            std::atomic<uint32_t>* cancelled_upto, int* launches, std::string& err) {
     RenderK P = Pin;
     const long long n_slots_ll = (long long)P.n_tiles * P.chunks * RTR_BLOCK;
     if (n_slots_ll > (1ll << 30)) return wf_fail(err, RTR_ERR_UNSUPPORTED, "path pool larger than 2^30 slots");
     WfState S{};
-    int rc = wf_alloc(pool, S, (int)n_slots_ll, sort, err);
+    int rc = wf_alloc(pool, S, (int)n_slots_ll, err);
     if (rc) return rc;
-    const bool media = trav == RT_TRAV_MEDIA || trav == RT_TRAV_PROGRAM;
-    const bool mis = integrator == RTR_INTEGRATOR_MIS;
+    const bool shadows = plan.has_lights && (integrator == RTR_INTEGRATOR_MIS || integrator == RTR_INTEGRATOR_NEE);
+    const bool split = plan.media && shadows;
     const dim3 block(RTR_BLOCK);
-    const int n_blocks = (S.n_slots + RTR_BLOCK - 1) / RTR_BLOCK;
-    const dim3 grid((unsigned)n_blocks); /* one slot per lane; kernels keep the grid-stride form */
+    const dim3 grid_all((unsigned)S.n_blocks);
+    const dim3 grid_cast((unsigned)std::max(1, std::min(S.n_blocks, plan.n_cus * RTR_WF_EXTEND_WAVES)));
+    const dim3 grid_shade((unsigned)std::max(1, std::min(S.n_blocks, plan.n_cus * 16)));
+    if ((rc = wf_lds_attr(wf_extend<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend<false>, plan.lds, err)) ||
+        (rc = wf_lds_attr(wf_connect<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_connect<false>, plan.lds, err)))
+        return rc;
     int n_launch = 0;
-    WF_HIP(hipMemsetAsync(S.n_live, 0, 8, stream));
-    hipLaunchKernelGGL(wf_init, grid, block, 0, stream, S, P);
+    *pool.h_live = (uint32_t)S.n_blocks;
+    hipLaunchKernelGGL(wf_init, grid_all, block, 0, stream, S, P);
     ++n_launch;
 
-#define WF_EXTEND_R(T, R)                                                                                \
+#define WF_SHADE_S(I, PH, M)                                                                             \
     do {                                                                                                 \
-        if ((rc = wf_lds_attr(wf_extend<T, true, R>, lds, err)) || (rc = wf_lds_attr(wf_extend<T, false, R>, lds, err))) \
-            return rc;                                                                                   \
-        if (sort)                                                                                        \
-            hipLaunchKernelGGL((wf_extend<T, true, R>), grid, block, lds, stream, sc, S, P, par);        \
+        if (plan.sort)                                                                                   \
+            hipLaunchKernelGGL((wf_shade<I, PH, M, true>), grid_shade, block, 0, stream, sc, S, P, par); \
         else                                                                                             \
-            hipLaunchKernelGGL((wf_extend<T, false, R>), grid, block, lds, stream, sc, S, P, par);       \
+            hipLaunchKernelGGL((wf_shade<I, PH, M, false>), grid_shade, block, 0, stream, sc, S, P, par); \
         ++n_launch;                                                                                      \
     } while (0)
-#define WF_EXTEND(T)                \
-    do {                            \
-        if (lean || quadlit)        \
-            WF_EXTEND_R(T, false);  \
-        else                        \
-            WF_EXTEND_R(T, true);   \
-    } while (0)
-#define WF_SHADE(I, PH, M)                                                                               \
-    do {                                                                                                 \
-        if (sort)                                                                                        \
-            hipLaunchKernelGGL((wf_shade<I, PH, M, true>), grid, block, 0, stream, sc, S, P, par);       \
-        else                                                                                             \
-            hipLaunchKernelGGL((wf_shade<I, PH, M, false>), grid, block, 0, stream, sc, S, P, par);      \
-        ++n_launch;                                                                                      \
-    } while (0)
-#define WF_CONNECT(T)                                                                                    \
-    do {                                                                                                 \
-        if ((rc = wf_lds_attr(wf_connect<T>, lds, err))) return rc;                                      \
-        hipLaunchKernelGGL(wf_connect<T>, grid, block, lds, stream, sc, S, P);                           \
-        ++n_launch;                                                                                      \
+/* material-set variants as in the megakernel: lean (RR / MIS), QuadLights only (MIS), everything */
+#define WF_SHADE(PH)                                                                    \
+    do {                                                                                \
+        switch (integrator) {                                                           \
+        case RTR_INTEGRATOR_RR:                                                         \
+            if (plan.lean)                                                              \
+                WF_SHADE_S(RTR_INTEGRATOR_RR, 0, RT_MS_LEAN);                           \
+            else                                                                        \
+                WF_SHADE_S(RTR_INTEGRATOR_RR, 0, RT_MS_FULL);                           \
+            break;                                                                      \
+        case RTR_INTEGRATOR_PATH: WF_SHADE_S(RTR_INTEGRATOR_PATH, 0, RT_MS_FULL); break; \
+        case RTR_INTEGRATOR_PBR: WF_SHADE_S(RTR_INTEGRATOR_PBR, 0, RT_MS_FULL); break;  \
+        case RTR_INTEGRATOR_NEE: WF_SHADE_S(RTR_INTEGRATOR_NEE, PH, RT_MS_FULL); break; \
+        default:                                                                        \
+            if (plan.lean && PH == 0)                                                   \
+                WF_SHADE_S(RTR_INTEGRATOR_MIS, 0, RT_MS_LEAN);                          \
+            else if (plan.quadlit)                                                      \
+                WF_SHADE_S(RTR_INTEGRATOR_MIS, PH, RT_MS_QUADLIT);                      \
+            else                                                                        \
+                WF_SHADE_S(RTR_INTEGRATOR_MIS, PH, RT_MS_FULL);                         \
+        }                                                                               \
     } while (0)
 
-    int iter = 0;
-    const int check = 32;
+    const int batch = 8;
+    int par = 0, iter = 0, n_batches = 0;
     bool cancelled = false;
     for (;;) {
-        for (int b = 0; b < check; ++b, ++iter) {
-            const int par = iter & 1;
-            if (trav == RT_TRAV_FLAT)
-                WF_EXTEND(RT_TRAV_FLAT);
-            else if (trav == RT_TRAV_FAST)
-                WF_EXTEND(RT_TRAV_FAST);
-            else if (trav == RT_TRAV_PROGRAM)
-                WF_EXTEND_R(RT_TRAV_PROGRAM, true);
-            else if (media)
-                WF_EXTEND_R(RT_TRAV_MEDIA, true);
+        for (int b = 0; b < batch; ++b, ++iter) {
+            if (plan.lean || plan.quadlit)
+                hipLaunchKernelGGL(wf_extend<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
             else
-                WF_EXTEND(RT_TRAV_EXACT);
-            if (!mis) {
-                if (lean)
-                    WF_SHADE(RTR_INTEGRATOR_RR, 0, RT_MS_LEAN);
-                else
-                    WF_SHADE(RTR_INTEGRATOR_RR, 0, RT_MS_FULL);
-            } else if (!media) {
-                if (lean)
-                    WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_LEAN);
-                else if (quadlit)
-                    WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_QUADLIT);
-                else
-                    WF_SHADE(RTR_INTEGRATOR_MIS, 0, RT_MS_FULL);
-                if (has_lights) {
-                    if (trav == RT_TRAV_FLAT)
-                        WF_CONNECT(RT_TRAV_FLAT);
-                    else if (trav == RT_TRAV_FAST)
-                        WF_CONNECT(RT_TRAV_FAST);
-                    else
-                        WF_CONNECT(RT_TRAV_EXACT);
-                }
+                hipLaunchKernelGGL(wf_extend<true>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+            ++n_launch;
+            if (!split) {
+                WF_SHADE(0);
             } else {
-                if (quadlit)
-                    WF_SHADE(RTR_INTEGRATOR_MIS, 1, RT_MS_QUADLIT);
-                else
-                    WF_SHADE(RTR_INTEGRATOR_MIS, 1, RT_MS_FULL);
-                if (has_lights) {
-                    if (trav == RT_TRAV_PROGRAM)
-                        WF_CONNECT(RT_TRAV_PROGRAM);
-                    else
-                        WF_CONNECT(RT_TRAV_MEDIA);
-                }
-                WF_SHADE(RTR_INTEGRATOR_MIS, 2, RT_MS_FULL);
+                WF_SHADE(1);
             }
+            if (shadows) {
+                if (plan.media)
+                    hipLaunchKernelGGL(wf_connect<true>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+                else
+                    hipLaunchKernelGGL(wf_connect<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+                ++n_launch;
+            }
+            if (split) WF_SHADE(2);
+            hipLaunchKernelGGL(wf_compact, dim3(1), dim3(1024), 0, stream, S, par);
+            ++n_launch;
+            par ^= 1;
         }
         WF_HIP(hipGetLastError());
-        WF_HIP(hipMemcpyAsync(pool.h_live, S.n_live, 4, hipMemcpyDeviceToHost, stream));
-        WF_HIP(hipStreamSynchronize(stream));
-        if (*pool.h_live == 0) break;
+        WF_HIP(hipEventRecord(pool.ev[n_batches & 1], stream));
+        ++n_batches;
+        if (n_batches >= 2) { /* wait for the batch before the one just enqueued: the GPU still has a full batch queued */
+            WF_HIP(hipEventSynchronize(pool.ev[n_batches & 1]));
+            if (__atomic_load_n(pool.h_live, __ATOMIC_ACQUIRE) == 0) break;
+        }
         if (cancelled_upto && cancelled_upto->load() >= P.render_id) {
             cancelled = true;
             break;
         }
     }
-#undef WF_EXTEND
-#undef WF_EXTEND_R
 #undef WF_SHADE
-#undef WF_CONNECT
-    hipLaunchKernelGGL(wf_finish, grid, block, 0, stream, S, P);
+#undef WF_SHADE_S
+    hipLaunchKernelGGL(wf_finish, grid_all, block, 0, stream, S, P);
     ++n_launch;
-    if (cancelled) { /* unfinished pixels have no sum yet: leave the caller's buffer untouched */
-        if (launches) *launches = n_launch;
-        return RTR_ERR_CANCELLED;
-    }
+    if (launches) *launches = n_launch;
+    if (cancelled) return RTR_ERR_CANCELLED; /* unfinished pixels have no sum yet: the caller's buffer stays untouched */
     ResolveK R{P, d_rgb, (long long)row_stride};
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), block, 0, stream, R);
     ++n_launch;

@@ -67,6 +67,7 @@ struct rtr_context {
     std::mutex cancel_mu;
     int n_materials = 0;
     int n_cus = 256; /* hipDeviceProp.multiProcessorCount */
+    bool machine_ok = false; /* the compiled scene fits the position word of the traversal machine (rt_machine.h) */
 };
 
 namespace {
@@ -475,8 +476,8 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, b
 int auto_chunks(int pipeline, double resident_slots, int n_tiles, int spp) {
     int chunks = 1;
     if (pipeline == RTR_PIPELINE_WAVEFRONT) { /* one pool slot per pixel and chunk: keep the pool small */
-        while ((long long)n_tiles * chunks < 4096 && chunks * 2 * 32 <= spp && chunks < 64) chunks *= 2;
-        return chunks;
+        while ((long long)n_tiles * chunks < 8192 && chunks * 2 * 16 <= spp && chunks < 64) chunks *= 2;
+        return chunks; /* about 2 M slots (0.5 GB of path state) where the image allows it */
     }
     double best = 0;
     for (int cand = 1; cand <= 64 && cand <= spp; cand *= 2) {
@@ -642,8 +643,17 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     if ((rc = upload(c, c->b_fexit, cs.exits.data(), sizeof(int32_t) * cs.exits.size()))) return rc;
     if ((rc = upload(c, c->b_fbvh, cs.bvh.data(), sizeof(FBvh) * cs.bvh.size()))) return rc;
     if ((rc = upload(c, c->b_fsub, cs.subs.data(), sizeof(FSub) * cs.subs.size()))) return rc;
-    if ((rc = upload(c, c->b_fstep, cs.steps.data(), sizeof(FStep) * cs.steps.size()))) return rc;
     info.program_steps = (int32_t)cs.steps.size();
+    /* the traversal machine of the wavefront stages always runs a step program: a scene without media is
+     * the one-step program "sub-scene 0" */
+    std::vector<FStep> dev_steps = cs.steps;
+    if (cs.ok && dev_steps.empty()) {
+        FStep whole{};
+        whole.kind = 0, whole.sub = 0;
+        dev_steps.push_back(whole);
+    }
+    if ((rc = upload(c, c->b_fstep, dev_steps.data(), sizeof(FStep) * dev_steps.size()))) return rc;
+    c->machine_ok = !dev_steps.empty() && dev_steps.size() < M_MAX_STEPS && cs.inst.size() < M_MAX_INSTANCES;
     bool any_tie = false;
     {
         std::vector<rtr_node> prims(cs.ref.size());
@@ -698,7 +708,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fsub = static_cast<const FSub*>(c->b_fsub.p);
     d.n_finst = cs.ok ? cs.subs[0].n_inst : 0;
     d.fstep = static_cast<const FStep*>(c->b_fstep.p);
-    d.n_fstep = (int32_t)cs.steps.size();
+    d.n_fstep = (int32_t)dev_steps.size();
     d.fstep_tail = cs.step_tail;
     d.fstep_pad = 0;
     d.nodes = static_cast<const rtr_node*>(c->b_nodes.p);
@@ -776,9 +786,10 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
 
     int pipeline = p->pipeline;
     if (pipeline == RTR_PIPELINE_AUTO) pipeline = RTR_PIPELINE_MEGAKERNEL;
-    if (pipeline == RTR_PIPELINE_WAVEFRONT && p->integrator != RTR_INTEGRATOR_RR && p->integrator != RTR_INTEGRATOR_MIS)
-        return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs integrators 1 (RR) and 4 (MIS) only");
     const int trav = pick_trav(c, p->flags);
+    if (pipeline == RTR_PIPELINE_WAVEFRONT && (!c->machine_ok || (trav != RT_TRAV_FLAT && trav != RT_TRAV_FAST && trav != RT_TRAV_PROGRAM)))
+        return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs the compiled traversals only: this graph (or "
+                                            "RTR_FLAG_REFERENCE_ORDER) needs the reference-order walk of the megakernel");
     int chunks = p->spp_chunks;
     if (chunks == 0) {
         /* workgroups of this kernel variant the chip holds at once (registers / LDS decide: 2-5 per CU) */
@@ -827,10 +838,16 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
-        const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
-        rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), c->ds.n_lights > 0, lean, c->quad_lights_only && !c->info.needs_uv,
-                              !lean && c->n_material_types > 1, trav, stack_bytes(c, trav), P, p->integrator, d_rgb,
-                              row_stride, c->stream, &c->cancelled_upto, &launches, c->err);
+        WavefrontPlan plan{};
+        plan.has_lights = c->ds.n_lights > 0;
+        plan.media = trav == RT_TRAV_PROGRAM;
+        plan.lean = c->lean_materials && !plan.media;
+        plan.quadlit = c->quad_lights_only && !c->info.needs_uv;
+        plan.sort = !plan.lean && c->n_material_types > 1;
+        plan.n_cus = c->n_cus;
+        plan.lds = stack_bytes(c, trav);
+        rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), plan, P, p->integrator, d_rgb, row_stride,
+                              c->stream, &c->cancelled_upto, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
         if (rc == RTR_ERR_CANCELLED) c->stats.cancelled = 1;
         c->stats.kernel_launches = launches;

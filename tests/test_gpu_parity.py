@@ -36,6 +36,23 @@ def _upload(ctx, sid):
     return sc
 
 
+def _wavefront_runs(sc):
+    """The wavefront pipeline runs the compiled traversals; graphs that need the reference-order walk
+    (hollow spheres, a medium under a transform) are the megakernel's."""
+    info = G.rtr.native.validate_scene(sc)
+    return info["fast_ok"] or info["program_steps"] > 0
+
+
+def _render_or_unsupported(ctx, sc, params):
+    """Render; a wavefront request for a graph that pipeline does not run must fail with RTR_ERR_UNSUPPORTED."""
+    if params.pipeline == A.PIPELINE_WAVEFRONT and (not _wavefront_runs(sc) or params.flags & A.FLAG_REFERENCE_ORDER):
+        with pytest.raises(G.rtr.RtrError) as e:
+            ctx.render(params)
+        assert e.value.code == A.RTR_ERR_UNSUPPORTED
+        return None
+    return ctx.render(params)
+
+
 def _close(a, b, rtol):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -236,15 +253,18 @@ def test_compiled_scene_equals_reference_order(ctx, sid):
     sets_uv = h & ~np.isin(exact["material"], sc.nodes["a"][sc.nodes["type"] == A.NODE_MOVING_SPHERE])
     for f in ("u", "v"):
         assert np.array_equal(_bits(fast[f][sets_uv]), _bits(exact[f][sets_uv])), f
-    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
-        integ = 1 if sid in (7, 1, 4) else 4  # 4 and 35: image textures, (u,v) rebuilt after the order-free cast
+    integ = 1 if sid in (7, 1, 4) else 4  # 4 and 35: image textures, (u,v) rebuilt after the order-free cast
+    b = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=A.PIPELINE_MEGAKERNEL,
+                                 flags=A.FLAG_REFERENCE_ORDER))
+    sb = ctx.stats()
+    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):  # compiled traversal, both pipelines
         a = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe))
         sa = ctx.stats()
-        b = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe,
-                                     flags=A.FLAG_REFERENCE_ORDER))
-        sb = ctx.stats()
-        assert np.array_equal(_bits(a), _bits(b))
+        assert np.array_equal(_bits(a), _bits(b)), pipe
         assert sa["closest_segments"] == sb["closest_segments"] and sa["shadow_segments"] == sb["shadow_segments"]
+    with pytest.raises(G.rtr.RtrError) as e:  # the wavefront stages run compiled traversals only
+        ctx.render(A.make_params(32, 32, 1, integrator=integ, pipeline=A.PIPELINE_WAVEFRONT, flags=A.FLAG_REFERENCE_ORDER))
+    assert e.value.code == A.RTR_ERR_UNSUPPORTED
 
 
 def rtr_info(sc):
@@ -273,16 +293,16 @@ def test_media_program_equals_reference_order(ctx, sid, integ):
             assert np.array_equal(prog[f][h], walk[f][h]), f
         for f in ("t", "p", "n"):
             assert np.array_equal(_bits(prog[f][h]), _bits(walk[f][h])), f
-    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
-        if pipe == A.PIPELINE_WAVEFRONT and integ == 3:
-            continue
-        a = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe))
+    b = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=A.PIPELINE_MEGAKERNEL,
+                                 flags=A.FLAG_REFERENCE_ORDER))
+    sb = ctx.stats()
+    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):  # the step program: lockstep (megakernel) and as the
+        a = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe))  # resumable machine (wavefront)
         sa = ctx.stats()
-        b = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=pipe,
-                                     flags=A.FLAG_REFERENCE_ORDER))
-        sb = ctx.stats()
-        assert np.array_equal(_bits(a), _bits(b))
-        assert sa["closest_segments"] == sb["closest_segments"] and sa["shadow_segments"] == sb["shadow_segments"]
+        assert np.array_equal(_bits(a), _bits(b)), pipe
+        assert sa["closest_segments"] == sb["closest_segments"], pipe
+        # a blocked shadow ray of the machine stops at its first hit once no medium is left to draw: same count
+        assert sa["shadow_segments"] == sb["shadow_segments"], pipe
 
 
 N1_CASES = [(7, 0, "img_scene07_i0_48_spp8.f64"), (23, 2, "img_scene23_i2_64_spp16.f64"),
@@ -319,9 +339,11 @@ def test_next_integrators(ctx, sid, integ, img_name):
     assert G.rel_l2(out, img) <= (1e-12 if sid in (7, 21) else REL_L2_BAR)
     ora, _ = G.oracle_render(sc, p, threads=0)
     assert G.rel_l2(out, ora) <= (1e-12 if sid in (7, 21) else REL_L2_BAR)
-    with pytest.raises(G.rtr.RtrError) as e:  # the wavefront stages exist for integrators 1 and 4
-        ctx.render(A.make_params(32, 32, 1, integrator=integ, pipeline=A.PIPELINE_WAVEFRONT))
-    assert e.value.code == A.RTR_ERR_UNSUPPORTED
+    # the wavefront stages run all five integrators: same bits as the megakernel
+    p.pipeline = A.PIPELINE_WAVEFRONT
+    wf = ctx.render(p)
+    assert ctx.stats()["pipeline"] == A.PIPELINE_WAVEFRONT
+    assert np.array_equal(_bits(wf), _bits(out))
 
 
 @pytest.mark.parametrize("sid", [15, 17, 18, 19, 24, 26])
@@ -358,7 +380,7 @@ def test_delta_and_environment_lights(ctx, sid):
         assert same.mean() >= 0.995
         assert np.all(_close(o["L"][same], grec["L"][same], 1e-9).all(axis=1))
         img, iinfo = G.image(img_name)
-        for pipe in ((A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT) if integ == 4 else (A.PIPELINE_MEGAKERNEL,)):
+        for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
             q = A.make_params(iinfo["width"], iinfo["height"], iinfo["spp"], integrator=integ, seed=iinfo["seed"],
                               pipeline=pipe)
             assert G.rel_l2(ctx.render(q), img) <= REL_L2_BAR
@@ -377,7 +399,9 @@ def test_every_other_reference_scene(ctx, sid):
     sc = _upload(ctx, sid)
     for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
         p = A.make_params(info["width"], info["height"], info["spp"], integrator=4, seed=info["seed"], pipeline=pipe)
-        out = ctx.render(p)
+        out = _render_or_unsupported(ctx, sc, p)
+        if out is None:
+            continue
         st = ctx.stats()
         assert st["samples"] == info["width"] * info["height"] * info["spp"]
         close = np.all(_close(out, img, 1e-9) | (np.abs(out - img) <= 1e-12), axis=-1)
@@ -462,10 +486,11 @@ def test_default_traversal_equals_reference_order_on_every_scene(ctx, sid):
     second["o"], second["d"] = first["p"][h], d
     both(second)
     integ = 4 if len(sc.lights) else 1
+    y = ctx.render(A.make_params(48, 32, 2, integrator=integ, seed=77, pipeline=A.PIPELINE_MEGAKERNEL,
+                                 flags=A.FLAG_REFERENCE_ORDER))
     for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
-        x = ctx.render(A.make_params(48, 32, 2, integrator=integ, seed=77, pipeline=pipe))
-        y = ctx.render(A.make_params(48, 32, 2, integrator=integ, seed=77, pipeline=pipe, flags=A.FLAG_REFERENCE_ORDER))
-        assert np.array_equal(_bits(x), _bits(y)), pipe
+        x = _render_or_unsupported(ctx, sc, A.make_params(48, 32, 2, integrator=integ, seed=77, pipeline=pipe))
+        assert x is None or np.array_equal(_bits(x), _bits(y)), pipe
 
 
 @pytest.mark.parametrize("sid", EVERY_SCENE)
@@ -478,10 +503,11 @@ def test_other_integrators_on_every_scene(ctx, sid):
     for integ in (0, 1, 2, 3):
         p = A.make_params(W, H, 3, integrator=integ, seed=5, max_depth=12 if integ == 0 else 50)
         ora, ost = G.oracle_render(sc, p, threads=0)
-        pipes = (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT) if integ == 1 else (A.PIPELINE_MEGAKERNEL,)
-        for pipe in pipes:
+        for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
             q = A.make_params(W, H, 3, integrator=integ, seed=5, max_depth=12 if integ == 0 else 50, pipeline=pipe)
-            out = ctx.render(q)
+            out = _render_or_unsupported(ctx, sc, q)
+            if out is None:
+                continue
             close = np.all(_close(out, ora, 1e-9) | (np.abs(out - ora) <= 1e-12), axis=-1)
             assert close.mean() >= 0.985, (integ, pipe, close.mean())
             assert G.rel_l2(out, ora) <= 5e-2 or np.abs(out - ora).max() <= 1e-12, (integ, pipe)
