@@ -32,16 +32,42 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def build_hip(force=False, verbose=False):
-    """Exact-arithmetic build: -ffp-contract=off keeps the reference's mul/add sequence."""
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+# translation units of librtr_hip.so: (object name, source, extra defines); compiled in parallel
+HIP_UNITS = [("capi", "rtr_capi.hip", []), ("mega_mis", "rtr_mega.hip", ["-DRTR_MEGA_GROUP=0"]),
+             ("mega_rr_path", "rtr_mega.hip", ["-DRTR_MEGA_GROUP=1"]), ("mega_pbr_nee", "rtr_mega.hip", ["-DRTR_MEGA_GROUP=2"]),
+             ("wavefront", "rtr_wavefront.hip", [])]
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    """Exact-arithmetic build: -ffp-contract=off keeps the reference's mul/add sequence.  The units are
+    compiled side by side (hipcc cross-compiles gfx950 without a GPU) and linked into one library."""
+    from concurrent.futures import ThreadPoolExecutor
     out = os.path.join(HERE, "librtr_hip.so")
-    if not force and not _newer(out, _sources(CSRC, (".hip", ".h"))):
+    sources = _sources(CSRC, (".hip", ".h"))
+    if not force and not extra_flags and not _newer(out, sources):
         return out
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wno-unused-value", "-I" + INC, "-I" + CSRC, os.path.join(CSRC, "rtr_capi.hip"), "-o", out]
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_unit(unit):
+        name, src, defs = unit
+        obj = os.path.join(objdir, name + ".o")
+        if not force and not extra_flags and not _newer(obj, sources):
+            return obj, ""
+        cmd = [hipcc()] + HIP_FLAGS + list(extra_flags) + defs + ["-I" + INC, "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr.decode()[-4000:]))
+        return obj, r.stderr.decode()
+
+    with ThreadPoolExecutor(max_workers=min(len(HIP_UNITS), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_unit, HIP_UNITS))
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", out], check=True)
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.run(cmd, check=True)
+        return out, "".join(log for _, log in results)
     return out
 
 

@@ -176,7 +176,8 @@ struct DScene {
     int32_t n_fstep;         /* steps of the ray-cast program of a scene with media (0 = none) */
     const struct FStep* fstep;
     int32_t fstep_tail;      /* first step after the last medium */
-    int32_t fstep_pad;
+    int32_t n_fvisit;        /* visits of the traversal machine's flattened program (rt_machine.h) */
+    const struct FVisit* fvisit;
 };
 
 /*

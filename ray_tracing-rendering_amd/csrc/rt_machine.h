@@ -5,22 +5,24 @@
  * Why.  run_program() keeps the 64 lanes of a wave in lockstep through the steps of the ray-cast
  * program; inside a box tree every lane then waits for the slowest one (scene 9: 4.9 inner nodes and
  * 1.7 primitive tests per lane and tree, but 33 loop iterations per wave -- lane utilisation 26 %).
- * Here every lane carries its own program position (step, pass, instance) and the wave alternates
+ * Here every lane carries its own position in the program and the wave alternates
  *
  *   tree phase     all lanes that are inside SOME box tree (not necessarily the same one) run the
  *                  while-while traversal loop together; the phase ends when enough lanes have left
  *                  their tree and wait for something else to do;
- *   advance phase  the waiting lanes move on -- next instance, next pass, next step, result written,
- *                  NEXT RAY FETCHED from the stage's queue (persistent threads) -- until each of them
- *                  is inside a tree again or the queue is empty.  Lanes at the same position are
- *                  served together (a waterfall over positions), so instance / step records still
- *                  come in through scalar loads exactly as in run_program().
+ *   service phase  the waiting lanes move on.  The program is flattened at upload into a list of
+ *                  VISITS (struct FVisit: one instance of one step, in execution order) and advancing
+ *                  is a data-driven loop -- "do the next visit" is the same instruction stream for
+ *                  every lane wherever it stands in the program, the visit record comes through a
+ *                  per-lane load -- that runs until each lane is inside a tree again or has finished
+ *                  its cast.  Finished lanes hand their result to the stage (client.finish) and take
+ *                  the NEXT RAY of the stage's queue (client.fetch): persistent threads.
  *
  * Lanes that are still inside a tree when the tree phase ends simply pause; their traversal state
  * (MLane) stays in registers.  A lane's arithmetic and its sequence of random draws are those of
  * run_program() / trace_fast(): same primitive tests in the same per-ray order, the constant_medium
  * draw under the same condition (constant_medium.h:62-103), so results are bit-identical
- * (tests: machine == run_program == reference-order walk on the golden hit vectors).
+ * (tests: wavefront == megakernel == reference-order walk on every golden scene).
  *
  * Shadow rays (ANYHIT) may stop at their first hit once no medium is left to draw in the program
  * (step >= fstep_tail): nothing after that point can change the random sequence or the answer.
@@ -29,15 +31,34 @@
 
 #include "rt_device.h"
 
-enum { M_IDLE = 0, M_FETCH = 1, M_PASS = 2, M_INST = 3, M_TREE = 4, M_END = 5, M_FINISH = 6 };
-/* position word: phase (3 bits) | pass (1 bit) | step (12 bits) | instance index into DScene::finst (16 bits) */
-RT_DEV int m_pos(int phase, int k, int pass, int ii) { return phase | (pass << 3) | (k << 4) | (ii << 16); }
-RT_DEV int m_phase(int pos) { return pos & 7; }
-RT_DEV int m_pass(int pos) { return (pos >> 3) & 1; }
-RT_DEV int m_step(int pos) { return (pos >> 4) & 0xFFF; }
-RT_DEV int m_inst(int pos) { return (pos >> 16) & 0xFFFF; }
-#define M_MAX_STEPS 4096
-#define M_MAX_INSTANCES 65536
+/* One instance visit of the ray-cast program, in execution order (built by rtr_upload_scene from
+ * FStep / FSub / FInst).  A medium step is walked twice (constant_medium.h:62-66): pass 1 restarts at
+ * `step_first`. */
+struct FVisit {
+    int32_t flags;
+    int32_t step;       /* index into DScene::fstep (a medium hit is reported as its step) */
+    int32_t inst;       /* index into DScene::finst (hit_inst of trace_fast; its box when FV_BOXES) */
+    int32_t step_first; /* first visit of this step */
+    int32_t xf_first, n_xf;
+    int32_t ref_first, n_ref;
+    int32_t bvh_root;   /* -1: scan the references linearly */
+    float bound;
+    double neg_inv_density; /* medium steps */
+    int32_t pad[4];
+};
+static_assert(sizeof(FVisit) == 64, "FVisit is one 64-byte record");
+#define FV_FIRST 1  /* first visit of its step */
+#define FV_LAST 2   /* last visit of its step */
+#define FV_MEDIUM 4 /* the step is a constant_medium (its sub-scene is the boundary) */
+#define FV_BOXES 8  /* the step's sub-scene has more than RT_FAST_NO_BOX_MAX instances: test instance boxes */
+#define FV_TAIL 16  /* step >= fstep_tail: no medium at or after this step */
+
+enum { M_IDLE = 0, M_FETCH = 1, M_ADV = 2, M_TREE = 3, M_FIN = 4 };
+/* mode bits next to the phase */
+#define M_PASS1 8       /* second boundary cast of a medium step */
+#define M_PASS_START 16 /* the next visit opens a pass (= one trace_fast() call of run_program()) */
+#define M_AFTER_TREE 32 /* the visit's box tree has just been left */
+#define M_EARLY 64      /* a shadow ray found its blocker where the first hit suffices */
 
 struct MLane {
     /* the ray (world frame) and the closest hit of the program so far */
@@ -46,7 +67,8 @@ struct MLane {
     Real best_t; /* run_program()'s tmax */
     int best_ref, best_inst, best_med;
     uint32_t rng;
-    int pos;
+    int state; /* phase | mode bits */
+    int j;     /* current visit */
     /* current pass = one trace_fast() call of run_program() */
     Real pass_lo, t1, t;
     int hit_ref, hit_inst, order;
@@ -57,7 +79,8 @@ struct MLane {
     int sp, node;
     int slot, aux; /* what the client is working on (opaque to the machine) */
 };
-
+RT_DEV int m_phase(const MLane& m) { return m.state & 7; }
+RT_DEV void m_set_phase(MLane& m, int phase) { m.state = phase; }
 RT_DEV bool m_any_hit(const MLane& m) { return m.best_ref >= 0 || m.best_med >= 0; }
 
 /* start a cast: ray (o, d, time) over [0.001, tmax] */
@@ -66,129 +89,142 @@ RT_DEV void m_begin(MLane& m, V3 o, V3 d, Real time, Real tmax, uint32_t rng) {
     m.best_t = tmax;
     m.best_ref = -1, m.best_inst = -1, m.best_med = -1;
     m.rng = rng;
-    m.pos = m_pos(M_PASS, 0, 0, 0);
+    m.j = 0;
+    m.state = M_ADV | M_PASS_START;
 }
 
 #define M_TMIN 0.001 /* both ray casts of the integrators start there (mis_path_integrator.h:37,213) */
 
-/* ---- advance phase: one position, uniform over the participating lanes ---------------------- */
-template <bool ANYHIT>
-RT_DEV void m_step_pass(const DScene& sc, MLane& m, const int k, const int pass) {
-    if (k >= sc.n_fstep) {
-        m.pos = M_FINISH;
-        return;
-    }
-    /* a shadow ray that is blocked may stop once no medium is left to draw (run_program: `ANY && any`) */
-    if (ANYHIT && k >= sc.fstep_tail && m_any_hit(m)) {
-        m.pos = M_FINISH;
-        return;
-    }
-    const FStep step = ld_const(sc.fstep, k);
-    const FSub sub = ld_const(sc.fsub, step.sub);
-    const bool medium = step.kind != 0;
-    if (pass == 0) m.pass_lo = medium ? -RT_INF : M_TMIN;
-    m.t = medium ? RT_INF : m.best_t;
-    m.hit_ref = -1, m.hit_inst = -1, m.order = -1;
-    m.pos = m_pos(M_INST, k, pass, sub.inst_first);
+/* a record of a read-only scene array through per-lane (divergent) loads */
+template <class T>
+RT_DEV T ld_lane(const T* base, int idx) {
+    static_assert(sizeof(T) % 8 == 0, "records are multiples of 8 bytes");
+    const __attribute__((address_space(1))) unsigned long long* src =
+        (const __attribute__((address_space(1))) unsigned long long*)(unsigned long long)(base + idx);
+    unsigned long long w[sizeof(T) / 8];
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 8; ++k) w[k] = src[k];
+    T v;
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
 }
 
+/* ---- service phase: advance every lane in M_ADV until it is inside a tree or its cast is finished ---- */
 template <bool ANYHIT>
-RT_DEV void m_step_inst(const DScene& sc, MLane& m, const int k, const int pass, const int ii) {
-    const FStep step = ld_const(sc.fstep, k);
-    const FSub sub = ld_const(sc.fsub, step.sub);
-    if (ii >= sub.inst_first + sub.n_inst) {
-        m.pos = m_pos(M_END, k, pass, 0);
-        return;
-    }
-    /* first hit suffices: shadow ray, geometry step, no medium at or after this step */
-    const bool first_hit_ends = ANYHIT && step.kind == 0 && k >= sc.fstep_tail;
-    const FInst I = ld_const(sc.finst, ii);
-    const bool use_boxes = sub.n_inst > RT_FAST_NO_BOX_MAX;
-    V3 lo = m.o, ld = m.d;
-    bool skip = false;
-    const int n_xf = I.n_xf;
-    if (n_xf) {
-        if (use_boxes) {
-            const V3 inv = mk(1.0 / m.d.x, 1.0 / m.d.y, 1.0 / m.d.z);
-            Real tn;
-            skip = !box_enter(I.bmin, I.bmax, m.o, inv, m.pass_lo, m.t, tn);
+RT_DEV void m_advance(const DScene& sc, const FVisit* visits, const int n_visits, MLane& m) {
+    while (m_phase(m) == M_ADV) {
+        if (m.j >= n_visits) { /* end of the program */
+            m_set_phase(m, M_FIN);
+            break;
         }
-        for (int x = 0; x < n_xf; ++x) {
-            const FXf xf = ld_const(sc.fxf, I.xf_first + x);
-            wrapper_enter(xf.type, xf.f, lo, ld);
-        }
-    }
-    int next = m_pos(M_INST, k, pass, ii + 1);
-    if (I.bvh_root < 0) {
-        const int r0 = I.ref_first, r1 = r0 + I.n_ref;
-        for (int r = r0; r < r1; ++r) {
-            Real t;
-            if (!skip && fast_ref_hit<true>(sc, r, lo, ld, m.time, m.pass_lo, m.t, t, m.order)) {
-                m.t = t;
-                m.hit_ref = r;
-                m.hit_inst = ii;
-                if (first_hit_ends) skip = true, next = m_pos(M_END, k, pass, 0);
+        const FVisit v = ld_lane(visits, m.j);
+        const bool medium = (v.flags & FV_MEDIUM) != 0;
+        /* first hit suffices: shadow ray in a geometry step with no medium at or after it */
+        const bool first_hit_ends = ANYHIT && (v.flags & FV_TAIL) != 0;
+        bool ended = (m.state & M_EARLY) != 0;
+        if (!(m.state & M_AFTER_TREE)) {
+            if (m.state & M_PASS_START) {
+                /* a shadow ray that is blocked may stop once no medium is left to draw (run_program: `ANY && any`) */
+                if (first_hit_ends && m_any_hit(m)) {
+                    m_set_phase(m, M_FIN);
+                    break;
+                }
+                if (!(m.state & M_PASS1)) m.pass_lo = medium ? -RT_INF : M_TMIN;
+                m.t = medium ? RT_INF : m.best_t;
+                m.hit_ref = -1, m.hit_inst = -1, m.order = -1;
+                m.state &= ~M_PASS_START;
+            }
+            V3 lo = m.o, ld = m.d;
+            bool skip = false;
+            if (v.n_xf) {
+                if (v.flags & FV_BOXES) {
+                    const FInst I = ld_lane(sc.finst, v.inst);
+                    const V3 inv = mk(1.0 / m.d.x, 1.0 / m.d.y, 1.0 / m.d.z);
+                    Real tn;
+                    skip = !box_enter(I.bmin, I.bmax, m.o, inv, m.pass_lo, m.t, tn);
+                }
+                for (int x = 0; x < v.n_xf; ++x) {
+                    const FXf xf = ld_lane(sc.fxf, v.xf_first + x);
+                    wrapper_enter(xf.type, xf.f, lo, ld);
+                }
+            }
+            if (v.bvh_root < 0) {
+                for (int q = 0; q < v.n_ref && !skip; ++q) {
+                    Real t;
+                    if (fast_ref_hit<true>(sc, v.ref_first + q, lo, ld, m.time, m.pass_lo, m.t, t, m.order)) {
+                        m.t = t;
+                        m.hit_ref = v.ref_first + q;
+                        m.hit_inst = v.inst;
+                        if (first_hit_ends) skip = true, ended = true;
+                    }
+                }
+            } else if (!skip) {
+                m.lo = lo, m.ld = ld;
+                m.br = boxray_make(lo, ld, v.bound);
+                m.tmin_f = float_below(m.pass_lo);
+                m.tmax_f = float_above(m.t);
+                m.sp = 0;
+                m.node = v.bvh_root;
+                m.state = (m.state & ~7) | M_TREE | M_AFTER_TREE;
+                break;
             }
         }
-    } else if (!skip) {
-        m.lo = lo, m.ld = ld;
-        m.br = boxray_make(lo, ld, I.bound);
-        m.tmin_f = float_below(m.pass_lo);
-        m.tmax_f = float_above(m.t);
-        m.sp = 0;
-        m.node = I.bvh_root;
-        next = m_pos(M_TREE, k, pass, ii);
-    }
-    m.pos = next;
-}
-
-RT_DEV void m_step_end(const DScene& sc, MLane& m, const int k, const int pass) {
-    const FStep step = ld_const(sc.fstep, k);
-    const bool medium = step.kind != 0;
-    const bool h = m.hit_ref >= 0;
-    int next = m_pos(M_PASS, k + 1, 0, 0);
-    if (!medium) {
-        if (h) m.best_t = m.t, m.best_ref = m.hit_ref, m.best_inst = m.hit_inst, m.best_med = -1;
-    } else if (h) {
-        if (pass == 0) {
-            m.t1 = m.t;
-            m.pass_lo = m.t + 0.0001;
-            next = m_pos(M_PASS, k, 1, 0);
-        } else { /* constant_medium.h:68-103 */
-            Real t1 = m.t1, t2 = m.t;
-            if (t1 < M_TMIN) t1 = M_TMIN;
-            if (t2 > m.best_t) t2 = m.best_t;
-            if (!(t1 >= t2)) {
-                if (t1 < 0) t1 = 0;
-                const Real ray_length = len(m.d);
-                const Real distance_inside_boundary = (t2 - t1) * ray_length;
-                const Real hit_distance = step.neg_inv_density * log(rng_next(m.rng));
-                if (!(hit_distance > distance_inside_boundary)) {
-                    m.best_t = t1 + hit_distance / ray_length;
-                    m.best_med = k, m.best_ref = -1, m.best_inst = -1;
+        m.state &= ~(M_AFTER_TREE | M_EARLY);
+        if (!(v.flags & FV_LAST) && !ended) {
+            ++m.j;
+            continue;
+        }
+        /* the pass is over (run_program(): what follows a trace_fast() call) */
+        const bool h = m.hit_ref >= 0;
+        int next = m.j + 1, mode = M_PASS_START;
+        if (!medium) {
+            if (h) m.best_t = m.t, m.best_ref = m.hit_ref, m.best_inst = m.hit_inst, m.best_med = -1;
+            if (ended) { /* blocked, and nothing left to draw */
+                m_set_phase(m, M_FIN);
+                break;
+            }
+        } else if (h) {
+            if (!(m.state & M_PASS1)) {
+                m.t1 = m.t;
+                m.pass_lo = m.t + 0.0001;
+                next = v.step_first;
+                mode = M_PASS_START | M_PASS1;
+            } else { /* constant_medium.h:68-103 */
+                Real t1 = m.t1, t2 = m.t;
+                if (t1 < M_TMIN) t1 = M_TMIN;
+                if (t2 > m.best_t) t2 = m.best_t;
+                if (!(t1 >= t2)) {
+                    if (t1 < 0) t1 = 0;
+                    const Real ray_length = len(m.d);
+                    const Real distance_inside_boundary = (t2 - t1) * ray_length;
+                    const Real hit_distance = v.neg_inv_density * log(rng_next(m.rng));
+                    if (!(hit_distance > distance_inside_boundary)) {
+                        m.best_t = t1 + hit_distance / ray_length;
+                        m.best_med = v.step, m.best_ref = -1, m.best_inst = -1;
+                    }
                 }
             }
         }
+        m.j = next;
+        m.state = M_ADV | mode;
     }
-    m.pos = next;
 }
 
 /* ---- tree phase --------------------------------------------------------------------------------
  * While-while traversal (trace_fast) for every lane whose phase is M_TREE, each in its own tree.
  * Ends when no lane is inside a tree any more, or when at least `wait_limit` lanes of the wave are
- * waiting for the advance phase (lanes that have left their tree + those that were waiting before). */
+ * waiting for the service phase. */
 template <bool ANYHIT>
-RT_DEV void m_tree_phase(const DScene& sc, MLane& m, const Stack st, const int wait_limit) {
-    const bool mine = m_phase(m.pos) == M_TREE;
+RT_DEV void m_tree_phase(const DScene& sc, const FVisit* visits, MLane& m, const Stack st, const int wait_limit) {
+    const bool mine = m_phase(m) == M_TREE;
     if (!__builtin_amdgcn_ballot_w64(mine)) return;
-    const int k = m_step(m.pos), ii = m_inst(m.pos);
-    /* a medium's step index is below fstep_tail, so `k >= fstep_tail` also says "geometry step" */
-    const bool first_hit_ends = ANYHIT && k >= sc.fstep_tail;
+    const int vflags = mine ? as_const(&visits->flags)[(size_t)m.j * (sizeof(FVisit) / 4)] : 0;
+    const int inst = mine ? as_const(&visits->inst)[(size_t)m.j * (sizeof(FVisit) / 4)] : 0;
+    const bool first_hit_ends = ANYHIT && (vflags & FV_TAIL) != 0;
     int node = mine ? m.node : RT_BVH_DONE;
     int sp = m.sp;
-    const int idle_before = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!mine && m_phase(m.pos) != M_IDLE));
     /* with few lanes left at the end of a queue the limit follows their number */
-    const int busy = __builtin_popcountll(__builtin_amdgcn_ballot_w64(m_phase(m.pos) != M_IDLE));
+    const int busy = __builtin_popcountll(__builtin_amdgcn_ballot_w64(m_phase(m) != M_IDLE));
     const int limit = wait_limit < (busy + 2) / 3 ? wait_limit : (busy + 2) / 3;
     bool ended_early = false;
     while (true) {
@@ -219,7 +255,7 @@ RT_DEV void m_tree_phase(const DScene& sc, MLane& m, const Stack st, const int w
                     m.t = t;
                     m.tmax_f = float_above(t);
                     m.hit_ref = r;
-                    m.hit_inst = ii;
+                    m.hit_inst = inst;
                     if (first_hit_ends) ended_early = true;
                 }
             }
@@ -228,50 +264,35 @@ RT_DEV void m_tree_phase(const DScene& sc, MLane& m, const Stack st, const int w
         const unsigned long long active = __builtin_amdgcn_ballot_w64(node != RT_BVH_DONE);
         if (!active) break;
         const int left_tree = __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && node == RT_BVH_DONE));
-        if (idle_before + left_tree >= limit) break;
+        if (left_tree >= limit) break;
     }
     if (mine) {
         m.node = node, m.sp = sp;
-        if (node == RT_BVH_DONE)
-            m.pos = ended_early ? m_pos(M_END, k, m_pass(m.pos), 0) : m_pos(M_INST, k, m_pass(m.pos), ii + 1);
+        if (node == RT_BVH_DONE) m.state = (m.state & ~7) | M_ADV | (ended_early ? M_EARLY : 0);
     }
 }
 
 /* ---- the machine ---------------------------------------------------------------------------------
  * Client (the stage kernel) supplies
- *     void fetch(MLane& m)    lanes in M_FETCH: take the next ray of the queue and m_begin() it, stay in
- *                             M_FETCH to be asked again, or go M_IDLE when the queue is empty (uniform call)
- *     void finish(MLane& m)   lanes in M_FINISH: consume the result, then M_FETCH
+ *     void finish(MLane& m)   called with the lanes in M_FIN active: consume the result, go M_FETCH
+ *     void fetch(MLane& m)    called with the lanes in M_FETCH active: take the next ray of the queue and
+ *                             m_begin() it, stay in M_FETCH to be asked again, or go M_IDLE (queue empty)
  * The loop returns when every lane is M_IDLE. */
 #ifndef RTR_MACHINE_WAIT
 #define RTR_MACHINE_WAIT 20 /* lanes of 64 that must be waiting before a tree phase is cut short */
 #endif
 
 template <bool ANYHIT, class Client>
-RT_DEV void m_run(const DScene& sc, MLane& m, const Stack st, Client& client) {
+RT_DEV void m_run(const DScene& sc, const FVisit* visits, const int n_visits, MLane& m, const Stack st, Client& client) {
     for (;;) {
-        m_tree_phase<ANYHIT>(sc, m, st, RTR_MACHINE_WAIT);
-        /* advance phase: serve positions one at a time until every lane is in a tree or idle */
+        m_tree_phase<ANYHIT>(sc, visits, m, st, RTR_MACHINE_WAIT);
         for (;;) {
-            const int ph = m_phase(m.pos);
-            const bool waiting = ph != M_TREE && ph != M_IDLE;
-            const unsigned long long todo = __builtin_amdgcn_ballot_w64(waiting);
-            if (!todo) break;
-            const int upos = __builtin_amdgcn_readlane(m.pos, __builtin_ctzll(todo));
-            if (m.pos == upos) { /* uniform position: the records below come through scalar loads */
-                const int uph = m_phase(upos), k = m_step(upos), pass = m_pass(upos), ii = m_inst(upos);
-                if (uph == M_INST)
-                    m_step_inst<ANYHIT>(sc, m, k, pass, ii);
-                else if (uph == M_PASS)
-                    m_step_pass<ANYHIT>(sc, m, k, pass);
-                else if (uph == M_END)
-                    m_step_end(sc, m, k, pass);
-                else if (uph == M_FINISH)
-                    client.finish(m);
-                else
-                    client.fetch(m);
-            }
+            m_advance<ANYHIT>(sc, visits, n_visits, m);
+            if (m_phase(m) == M_FIN) client.finish(m);
+            while (__builtin_amdgcn_ballot_w64(m_phase(m) == M_FETCH))
+                if (m_phase(m) == M_FETCH) client.fetch(m);
+            if (!__builtin_amdgcn_ballot_w64(m_phase(m) == M_ADV)) break;
         }
-        if (!__builtin_amdgcn_ballot_w64(m_phase(m.pos) != M_IDLE)) break;
+        if (!__builtin_amdgcn_ballot_w64(m_phase(m) != M_IDLE)) break;
     }
 }

@@ -40,9 +40,8 @@
  */
 #pragma once
 
-#include "rt_kernels.h"
+#include "rt_launch.h"
 #include "rt_machine.h"
-#include "rtr_hip_test.h"
 
 #include <algorithm>
 #include <atomic>
@@ -79,21 +78,15 @@ struct WfState {
     int n_slots, n_blocks;
 };
 
-struct WavefrontPool {
-    void* slab = nullptr;
-    size_t slab_bytes = 0;
-    uint32_t* h_live = nullptr; /* pinned + mapped */
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    void release() {
-        if (slab) (void)hipFree(slab);
-        if (h_live) (void)hipHostFree(h_live);
-        for (hipEvent_t& e : ev) {
-            if (e) (void)hipEventDestroy(e);
-            e = nullptr;
-        }
-        slab = nullptr, slab_bytes = 0, h_live = nullptr;
+void WavefrontPool::release() {
+    if (slab) (void)hipFree(slab);
+    if (h_live) (void)hipHostFree(h_live);
+    for (hipEvent_t& e : ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
     }
-};
+    slab = nullptr, slab_bytes = 0, h_live = nullptr;
+}
 
 RT_DEV V3 ldv(const double* x, const double* y, const double* z, int i) { return mk(x[i], y[i], z[i]); }
 RT_DEV void stv(double* x, double* y, double* z, int i, V3 v) { x[i] = v.x, y[i] = v.y, z[i] = v.z; }
@@ -249,7 +242,7 @@ struct ExtendClient {
         bool exhausted;
         const int slot = walk.take(exhausted);
         if (exhausted) {
-            m.pos = M_IDLE;
+            m_set_phase(m, M_IDLE);
             return;
         }
         if (slot < 0) return;
@@ -323,7 +316,7 @@ struct ExtendClient {
             S.flags[slot] = flags | WF_HIT;
         }
         S.rng[slot] = m.rng;
-        m.pos = M_FETCH;
+        m_set_phase(m, M_FETCH);
     }
 };
 
@@ -340,8 +333,8 @@ __global__ void __launch_bounds__(RTR_BLOCK, RTR_WF_EXTEND_WAVES)
     const Stack st{lds_stack + threadIdx.x};
     ExtendClient<RICH> client{sc, S, P, block_walk(cursors, S, parity, true), 0u};
     MLane m;
-    m.pos = M_FETCH;
-    m_run<false>(sc, m, st, client);
+    m_set_phase(m, M_FETCH);
+    m_run<false>(sc, sc.fvisit, sc.n_fvisit, m, st, client);
     const unsigned long long c = wave_sum(client.n_closest);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[1], c);
 }
@@ -358,7 +351,7 @@ struct ConnectClient {
         bool exhausted;
         const int slot = walk.take(exhausted);
         if (exhausted) {
-            m.pos = M_IDLE;
+            m_set_phase(m, M_IDLE);
             return;
         }
         if (slot < 0) return;
@@ -375,7 +368,7 @@ struct ConnectClient {
         const int slot = m.slot;
         if (MEDIA) S.rng[slot] = m.rng;
         if (!m_any_hit(m)) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
-        m.pos = M_FETCH;
+        m_set_phase(m, M_FETCH);
     }
 };
 
@@ -388,8 +381,8 @@ __global__ void __launch_bounds__(RTR_BLOCK, RTR_WF_EXTEND_WAVES)
     const Stack st{lds_stack + threadIdx.x};
     ConnectClient<MEDIA> client{sc, S, block_walk(cursors, S, parity, false), 0u};
     MLane m;
-    m.pos = M_FETCH;
-    m_run<true>(sc, m, st, client);
+    m_set_phase(m, M_FETCH);
+    m_run<true>(sc, sc.fvisit, sc.n_fvisit, m, st, client);
     const unsigned long long c = wave_sum(client.n_shadow);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[2], c);
 }
@@ -591,18 +584,12 @@ inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
     return RTR_OK;
 }
 
-struct WavefrontPlan {
-    bool has_lights, lean, quadlit, sort, media;
-    int n_cus;
-    size_t lds; /* traversal stack of the extend / connect stages */
-};
-
 /* Enqueues the whole render on `stream`.  The host stays at most two batches of iterations ahead of
  * the GPU and returns once the published number of live blocks is zero (everything it enqueued past that
  * point finds empty lists); it does not wait for the stream to drain. */
-inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan& plan, const RenderK& Pin,
-                            int integrator, double* d_rgb, int64_t row_stride, hipStream_t stream,
-                            std::atomic<uint32_t>* cancelled_upto, int* launches, std::string& err) {
+int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan& plan, const RenderK& Pin, int integrator,
+                     double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<uint32_t>* cancelled_upto,
+                     int* launches, std::string& err) {
     RenderK P = Pin;
     const long long n_slots_ll = (long long)P.n_tiles * P.chunks * RTR_BLOCK;
     if (n_slots_ll > (1ll << 30)) return wf_fail(err, RTR_ERR_UNSUPPORTED, "path pool larger than 2^30 slots");
@@ -700,7 +687,7 @@ inline int wavefront_render(WavefrontPool& pool, const DScene* sc, const Wavefro
     if (launches) *launches = n_launch;
     if (cancelled) return RTR_ERR_CANCELLED; /* unfinished pixels have no sum yet: the caller's buffer stays untouched */
     ResolveK R{P, d_rgb, (long long)row_stride};
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), block, 0, stream, R);
+    rtr_launch_resolve(R, stream);
     ++n_launch;
     WF_HIP(hipGetLastError());
     if (launches) *launches = n_launch;

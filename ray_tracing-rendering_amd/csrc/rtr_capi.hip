@@ -3,9 +3,11 @@
  * kernels of rt_kernels.h.  Host side only: scene validation and upload, launch geometry,
  * workspace, cancel, statistics.  Built by hipcc for gfx950 into librtr_hip.so.
  */
+#define RTR_TU_CAPI
 #include "rt_compile.h"
 #include "rt_kernels.h"
-#include "rt_wavefront.h"
+#include "rt_launch.h"
+#include "rt_machine.h"
 #include "rtr_hip_test.h"
 
 #include <atomic>
@@ -39,7 +41,7 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit;
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool force_exact = false;
@@ -393,78 +395,27 @@ int set_lds(rtr_context* c, K kernel, size_t bytes) {
     return RTR_OK;
 }
 
-/* `dry`: only what can fail without touching the stream (the LDS size check / attribute) */
+/* `dry`: only what can fail without touching the stream (the LDS size check / attribute, the occupancy query) */
 int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu = nullptr) {
+    MegaLaunch L{};
     /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
-    const int trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
-    const int stack_words = (int)(stack_bytes(c, trav) / (RTR_BLOCK * sizeof(int)));
-    const size_t lds = stack_bytes(c, trav) + (size_t)park_words(integrator, trav) * RTR_BLOCK * sizeof(double);
-    const DScene* dsc = static_cast<const DScene*>(c->b_dscene.p);
-    const dim3 grid((unsigned)(P.n_tiles * P.chunks)), block(RTR_BLOCK);
-    const bool lean = c->lean_materials && trav != RT_TRAV_MEDIA && trav != RT_TRAV_PROGRAM;
-    const bool quadlit = c->quad_lights_only && !c->info.needs_uv;
-#define RTR_LAUNCH(I, T, M)                                                                        \
-    do {                                                                                           \
-        int rc_ = set_lds(c, k_mega<I, T, M>, lds);                                                \
-        if (rc_) return rc_;                                                                       \
-        if (!dry) hipLaunchKernelGGL((k_mega<I, T, M>), grid, block, lds, c->stream, dsc, P, stack_words); \
-        if (dry && blocks_per_cu)                                                                  \
-            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_mega<I, T, M>, RTR_BLOCK, lds)); \
-    } while (0)
-/* FULLQ = the variant for "every material, QuadLights only" (the RR integrator has no light code) */
-#define RTR_LAUNCH_T(I, FULLQ)                                              \
-    do {                                                                    \
-        if (trav == RT_TRAV_FLAT) {                                         \
-            if (lean)                                                       \
-                RTR_LAUNCH(I, RT_TRAV_FLAT, RT_MS_LEAN);                    \
-            else if (quadlit)                                               \
-                RTR_LAUNCH(I, RT_TRAV_FLAT, FULLQ);                         \
-            else                                                            \
-                RTR_LAUNCH(I, RT_TRAV_FLAT, RT_MS_FULL);                    \
-        } else if (trav == RT_TRAV_FAST) {                                  \
-            if (lean)                                                       \
-                RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_LEAN);                    \
-            else if (quadlit)                                               \
-                RTR_LAUNCH(I, RT_TRAV_FAST, FULLQ);                         \
-            else                                                            \
-                RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);                    \
-        } else if (trav == RT_TRAV_PROGRAM) {                               \
-            if (quadlit)                                                    \
-                RTR_LAUNCH(I, RT_TRAV_PROGRAM, FULLQ);                      \
-            else                                                            \
-                RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);                 \
-        } else if (trav == RT_TRAV_MEDIA) {                                 \
-            RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);                       \
-        } else {                                                            \
-            if (lean)                                                       \
-                RTR_LAUNCH(I, RT_TRAV_EXACT, RT_MS_LEAN);                   \
-            else                                                            \
-                RTR_LAUNCH(I, RT_TRAV_EXACT, RT_MS_FULL);                   \
-        }                                                                   \
-    } while (0)
-/* integrators 0 / 2 / 3: generic material set; the media kernel also serves the
- * reference-order traversal of scenes without media */
-#define RTR_LAUNCH_N1(I)                                   \
-    do {                                                   \
-        if (trav == RT_TRAV_FAST)                          \
-            RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);       \
-        else if (trav == RT_TRAV_PROGRAM)                  \
-            RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);    \
-        else                                               \
-            RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);      \
-    } while (0)
+    L.trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
+    L.integrator = integrator;
+    L.stack_words = (int)(stack_bytes(c, L.trav) / (RTR_BLOCK * sizeof(int)));
+    L.lds = stack_bytes(c, L.trav) + (size_t)park_words(integrator, L.trav) * RTR_BLOCK * sizeof(double);
+    L.dsc = static_cast<const DScene*>(c->b_dscene.p);
+    L.lean = c->lean_materials && L.trav != RT_TRAV_MEDIA && L.trav != RT_TRAV_PROGRAM;
+    L.quadlit = c->quad_lights_only && !c->info.needs_uv;
+    L.stream = c->stream;
+    L.P = P;
+    L.dry = dry;
+    L.blocks_per_cu = blocks_per_cu;
     switch (integrator) {
-    case RTR_INTEGRATOR_MIS: RTR_LAUNCH_T(RTR_INTEGRATOR_MIS, RT_MS_QUADLIT); break;
-    case RTR_INTEGRATOR_RR: RTR_LAUNCH_T(RTR_INTEGRATOR_RR, RT_MS_FULL); break;
-    case RTR_INTEGRATOR_PATH: RTR_LAUNCH_N1(RTR_INTEGRATOR_PATH); break;
-    case RTR_INTEGRATOR_PBR: RTR_LAUNCH_N1(RTR_INTEGRATOR_PBR); break;
-    default: RTR_LAUNCH_N1(RTR_INTEGRATOR_NEE); break;
+    case RTR_INTEGRATOR_MIS: return rtr_mega_launch_mis(L, c->err);
+    case RTR_INTEGRATOR_RR:
+    case RTR_INTEGRATOR_PATH: return rtr_mega_launch_rr_path(L, c->err);
+    default: return rtr_mega_launch_pbr_nee(L, c->err);
     }
-#undef RTR_LAUNCH_N1
-#undef RTR_LAUNCH_T
-#undef RTR_LAUNCH
-    if (!dry) HIPCHK(c, hipGetLastError());
-    return RTR_OK;
 }
 
 /* auto chunking.  A workgroup renders one tile for one chunk of the samples.  More chunks = more, shorter
@@ -509,6 +460,10 @@ int finish_stats(rtr_context* c) {
 }
 
 } // namespace
+
+void rtr_launch_resolve(const ResolveK& R, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)R.r.n_tiles), dim3(RTR_BLOCK), 0, stream, R);
+}
 
 extern "C" {
 
@@ -594,7 +549,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_done, &c->b_stats, &c->b_cancel, &c->b_test, &c->b_stage,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -653,7 +608,26 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
         dev_steps.push_back(whole);
     }
     if ((rc = upload(c, c->b_fstep, dev_steps.data(), sizeof(FStep) * dev_steps.size()))) return rc;
-    c->machine_ok = !dev_steps.empty() && dev_steps.size() < M_MAX_STEPS && cs.inst.size() < M_MAX_INSTANCES;
+    /* ... flattened into instance visits in execution order */
+    std::vector<FVisit> visits;
+    for (size_t k = 0; k < dev_steps.size(); ++k) {
+        const FStep& st = dev_steps[k];
+        const FSub& sub = cs.subs[st.sub];
+        const int first = (int)visits.size();
+        for (int q = 0; q < sub.n_inst; ++q) {
+            const FInst& I = cs.inst[sub.inst_first + q];
+            FVisit v{};
+            v.flags = (q == 0 ? FV_FIRST : 0) | (q == sub.n_inst - 1 ? FV_LAST : 0) | (st.kind != 0 ? FV_MEDIUM : 0) |
+                      (sub.n_inst > RT_FAST_NO_BOX_MAX ? FV_BOXES : 0) | ((int)k >= cs.step_tail ? FV_TAIL : 0);
+            v.step = (int32_t)k, v.inst = sub.inst_first + q, v.step_first = first;
+            v.xf_first = I.xf_first, v.n_xf = I.n_xf, v.ref_first = I.ref_first, v.n_ref = I.n_ref;
+            v.bvh_root = I.bvh_root, v.bound = I.bound;
+            v.neg_inv_density = st.neg_inv_density;
+            visits.push_back(v);
+        }
+    }
+    if ((rc = upload(c, c->b_fvisit, visits.data(), sizeof(FVisit) * visits.size()))) return rc;
+    c->machine_ok = !visits.empty();
     bool any_tie = false;
     {
         std::vector<rtr_node> prims(cs.ref.size());
@@ -710,7 +684,8 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fstep = static_cast<const FStep*>(c->b_fstep.p);
     d.n_fstep = (int32_t)dev_steps.size();
     d.fstep_tail = cs.step_tail;
-    d.fstep_pad = 0;
+    d.fvisit = static_cast<const FVisit*>(c->b_fvisit.p);
+    d.n_fvisit = (int32_t)visits.size();
     d.nodes = static_cast<const rtr_node*>(c->b_nodes.p);
     d.list_children = static_cast<const int32_t*>(c->b_kids.p);
     d.materials = static_cast<const rtr_material*>(c->b_mats.p);
@@ -854,7 +829,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     } else {
         if ((rc = launch_mega(c, P, p->integrator, trav, false))) return rc;
         ResolveK R{P, d_rgb, (long long)row_stride};
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)P.n_tiles), dim3(RTR_BLOCK), 0, c->stream, R);
+        rtr_launch_resolve(R, c->stream);
         HIPCHK(c, hipGetLastError());
         c->stats.kernel_launches = 2;
     }

@@ -1,10 +1,16 @@
 #!/bin/bash
-# Rebuild librtr_hip.so for gfx950 and print the per-kernel register report.
+# Rebuild librtr_hip.so for gfx950 (translation units in parallel) and print the per-kernel register report.
+#   tools/build_hip.sh [extra hipcc flags, e.g. -DRTR_MACHINE_WAIT=16]
 cd "$(dirname "$0")/.." || exit 1
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-value \
-  -Iinclude -Iray_tracing-rendering_amd/csrc ray_tracing-rendering_amd/csrc/rtr_capi.hip \
-  -o ray_tracing-rendering_amd/librtr_hip.so -Rpass-analysis=kernel-resource-usage "$@" 2>/tmp/rtr_build.log
+python3 - "$@" <<'PY'
+import importlib, sys
+b = importlib.import_module("ray_tracing-rendering_amd.build")
+try:
+    out, log = b.build_hip(force=True, verbose=True, extra_flags=tuple(sys.argv[1:]))
+except RuntimeError as e:
+    print(e); sys.exit(1)
+open("/tmp/rtr_build.log", "w").write(log)
+PY
 rc=$?
-grep -E "error|warning: v" -A6 /tmp/rtr_build.log | head -40
-python3 tools/kres.py /tmp/rtr_build.log
+[ $rc -eq 0 ] && python3 tools/kres.py /tmp/rtr_build.log
 exit $rc
