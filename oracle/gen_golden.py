@@ -156,7 +156,46 @@ def sha(path):
         return hashlib.sha256(f.read()).hexdigest()
 
 
+def png_fixtures(manifest, note):
+    """SURVEY 8f N3: the reference's own output stage (Renderer::write_color_to_buffer + RenderBuffer::save_to_png,
+    the PNG read back with its stb_image) on linear images: two golden renders and one synthetic image of edge
+    values (0, denormal-small, values either side of every k/255 step after the sqrt, 1, > 1, huge)."""
+    import numpy as np
+    edge = np.zeros((8, 32, 3), dtype="<f8")
+    vals = [0.0, 1e-300, 1e-9, 0.25, 0.999999, 1.0, 1.0000001, 4.0, 1e300]
+    for k in range(0, 256, 3):  # g = k / 255 in gamma space -> linear g*g, nudged either side of the step
+        g = k / 255.0
+        vals += [np.nextafter(g * g, 0.0), g * g, np.nextafter(g * g, 2.0)]
+    flat = edge.reshape(-1)
+    flat[:len(vals)] = vals[:flat.size]
+    edge.tofile(os.path.join(GOLD, "png_edge_in.f64"))
+    manifest["files"]["png_edge_in.f64"] = {"argv": ["gen_golden.py: synthetic linear image 32x8"], "info": {},
+                                            "sha256": sha(os.path.join(GOLD, "png_edge_in.f64")),
+                                            "bytes": edge.nbytes, "width": 32, "height": 8}
+    for src, w, h in (("img_scene21_i4_64_spp16.f64", 64, 64), ("img_scene23_i4_64_spp16.f64", 64, 36),
+                      ("png_edge_in.f64", 32, 8)):
+        if src.startswith("img_"):
+            w, h = manifest["files"][src]["width"], manifest["files"][src]["height"]
+        name = "png_" + src.replace("img_", "").replace("png_", "").replace(".f64", "") + ".rgb8"
+        cmd, info = run("png", os.path.join(GOLD, src), w, h, os.path.join(GOLD, name))
+        cmd[2] = src
+        note(name, cmd, info, source=src, width=w, height=h)
+
+
 def main():
+    if "--add-png" in sys.argv:  # only the N3 fixtures, into the existing manifest
+        subprocess.run(["make", "-C", HERE, "_ref/ref_harness"], check=True)
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+
+        def note(name, cmd, info, **extra):
+            p = os.path.join(GOLD, name)
+            manifest["files"][name] = {"argv": [os.path.basename(cmd[0])] + cmd[1:-1] + [name], "info": info,
+                                       "sha256": sha(p), "bytes": os.path.getsize(p), **extra}
+        png_fixtures(manifest, note)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return 0
     if not os.path.exists(HARNESS):
         subprocess.run(["make", "-C", HERE, "_ref/ref_harness"], check=True)
     os.makedirs(GOLD, exist_ok=True)
@@ -338,6 +377,8 @@ def main():
     name = "img_scene21_i4_128_spp32.f64"
     cmd, info = run("render", 21, 4, 128, 32, 7, SCENE_SEED, os.path.join(GOLD, name), 8)
     note(name, cmd, info, scene=21, integrator=4, width=128, height=info["height"], spp=32, seed=7)
+
+    png_fixtures(manifest, note)
 
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -18,6 +18,10 @@
  *   lights      <scene> <scene_seed> <n_per_light> <gen_seed> <out.bin>
  *   rng         <out.bin>
  *   time        <scene> <integ> <W> <spp>                  unseeded Renderer::render timing
+ *   png         <in.f64> <W> <H> <out.rgb8>                the reference's own output stage on a linear image:
+ *                                                          Renderer::write_color_to_buffer (renderer.h:126-140) +
+ *                                                          RenderBuffer::save_to_png (render_buffer.h:35-55), the file
+ *                                                          decoded again with the reference's stb_image
  *
  * The pixel loop of `render`/`li` restates renderer/renderer.h:69-83 (the only
  * reference lines not executed verbatim): per (pixel, sample) it sets the RNG
@@ -756,6 +760,36 @@ static int cmd_rng(const char* path) {
 #endif /* !RTR_REF_UNSEEDED */
 
 #ifdef RTR_REF_WITH_RENDERER
+/* N3 pin: linear mean radiance (H x W x 3 doubles, row 0 = bottom row, as `render` writes it) through the
+ * reference's own gamma / clamp store and PNG writer; the PNG is read back with the reference's stb_image and
+ * its 8-bit pixels (top row first, as in the file) are the fixture */
+static int cmd_png(const char* in_path, int W, int H, const char* out_path) {
+    std::vector<double> img((size_t)W * H * 3);
+    FILE* f = std::fopen(in_path, "rb");
+    if (!f || std::fread(img.data(), sizeof(double), img.size(), f) != img.size()) die("cannot read the linear image");
+    std::fclose(f);
+    RenderBuffer buf(W, H);
+    Renderer renderer;
+    for (int j = 0; j < H; ++j)
+        for (int i = 0; i < W; ++i) {
+            const double* px = &img[((size_t)j * W + i) * 3];
+            renderer.write_color_to_buffer(buf, i, j, color(px[0], px[1], px[2]), 1); /* mean already: scale = 1 */
+        }
+    const std::string tmp = std::string(out_path) + ".tmp.png";
+    if (!buf.save_to_png(tmp)) die("save_to_png failed");
+    int w = 0, h = 0, n = 0;
+    unsigned char* data = stbi_load(tmp.c_str(), &w, &h, &n, 3);
+    if (!data || w != W || h != H) die("cannot read the PNG back");
+    f = std::fopen(out_path, "wb");
+    if (!f) die("cannot open output");
+    std::fwrite(data, 1, (size_t)W * H * 3, f);
+    std::fclose(f);
+    stbi_image_free(data);
+    std::remove(tmp.c_str());
+    std::printf("{\"width\": %d, \"height\": %d, \"channels_in_file\": %d}\n", W, H, n);
+    return 0;
+}
+
 /* the reference's own Renderer::render, exactly as main.cpp:78-102,115 minus SDL */
 static int cmd_time(int scene_id, int integ, int W, int spp) {
     SceneConfig cfg = select_scene(scene_id);
@@ -789,6 +823,7 @@ int main(int argc, char** argv) {
     auto U = [&](int k) { return (uint32_t)std::strtoul(argv[k], nullptr, 0); };
 #ifdef RTR_REF_WITH_RENDERER
     if (c == "time" && argc == 6) return cmd_time(I(2), I(3), I(4), I(5));
+    if (c == "png" && argc == 6) return cmd_png(argv[2], I(3), I(4), argv[5]);
 #endif
 #ifndef RTR_REF_UNSEEDED
     if (c == "info" && argc == 3) return cmd_info(I(2));

@@ -39,6 +39,8 @@ struct WavefrontPool {
 };
 struct WavefrontPlan {
     bool has_lights, lean, quadlit, sort, media;
+    bool machine; /* casting stages as persistent threads on the traversal machine instead of lockstep waves */
+    int trav;     /* RT_TRAV_FLAT / RT_TRAV_FAST / RT_TRAV_PROGRAM */
     int n_cus;
     size_t lds; /* traversal stack of the extend / connect stages */
 };

@@ -93,6 +93,24 @@ RT_DEV void m_begin(MLane& m, V3 o, V3 d, Real time, Real tmax, uint32_t rng) {
     m.state = M_ADV | M_PASS_START;
 }
 
+#ifdef RTR_MACHINE_STATS /* debug build: wave-level loop trips and the lanes that took part in them */
+struct MStats {
+    unsigned long long tree_trips, tree_lanes, inner_trips, inner_lanes, leaf_trips, leaf_lanes, adv_trips, adv_lanes,
+        fin_trips, fin_lanes, fetch_trips, fetch_lanes;
+};
+__device__ MStats g_mstats;
+#define M_STAT(field, pred)                                                                         \
+    do {                                                                                            \
+        const unsigned long long b_ = __builtin_amdgcn_ballot_w64(pred);                            \
+        if (b_ && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {       \
+            atomicAdd(&g_mstats.field##_trips, 1ull);                                               \
+            atomicAdd(&g_mstats.field##_lanes, (unsigned long long)__builtin_popcountll(b_));       \
+        }                                                                                           \
+    } while (0)
+#else
+#define M_STAT(field, pred) do { } while (0)
+#endif
+
 #define M_TMIN 0.001 /* both ray casts of the integrators start there (mis_path_integrator.h:37,213) */
 
 /* a record of a read-only scene array through per-lane (divergent) loads */
@@ -113,6 +131,7 @@ RT_DEV T ld_lane(const T* base, int idx) {
 template <bool ANYHIT>
 RT_DEV void m_advance(const DScene& sc, const FVisit* visits, const int n_visits, MLane& m) {
     while (m_phase(m) == M_ADV) {
+        M_STAT(adv, true);
         if (m.j >= n_visits) { /* end of the program */
             m_set_phase(m, M_FIN);
             break;
@@ -225,31 +244,43 @@ RT_DEV void m_tree_phase(const DScene& sc, const FVisit* visits, MLane& m, const
     int sp = m.sp;
     /* with few lanes left at the end of a queue the limit follows their number */
     const int busy = __builtin_popcountll(__builtin_amdgcn_ballot_w64(m_phase(m) != M_IDLE));
-    const int limit = wait_limit < (busy + 2) / 3 ? wait_limit : (busy + 2) / 3;
+    const int limit = wait_limit < (busy + 1) / 2 ? wait_limit : (busy + 1) / 2;
     bool ended_early = false;
     while (true) {
-        while (node >= 0) {
-            const NodeRegs b = load_node(sc.fbvh, node);
-            float tl, tr;
-            const bool hl = boxray_hit(m.br, b.lmin, b.lmax, m.tmin_f, m.tmax_f, tl);
-            const bool hr = boxray_hit(m.br, b.rmin, b.rmax, m.tmin_f, m.tmax_f, tr);
-            const int cl = b.left, cr = b.right;
-            if (hl && hr) { /* nearer child first */
-                const bool left_first = tl <= tr;
-                st.put(sp++, left_first ? cr : cl);
-                node = left_first ? cl : cr;
-            } else if (hl) {
-                node = cl;
-            } else if (hr) {
-                node = cr;
-            } else {
-                node = sp > 0 ? st.get(--sp) : RT_BVH_DONE;
+        M_STAT(tree, node != RT_BVH_DONE);
+        /* Descend.  A lane that has reached a leaf waits there; the leaves are served once no lane is at an
+         * inner node any more or half of the lanes inside a tree wait at one -- so neither the box tests nor the
+         * (expensive, double precision) primitive tests below run for a handful of lanes while the others idle. */
+        for (;;) {
+            const unsigned long long at_inner = __builtin_amdgcn_ballot_w64(node >= 0);
+            if (!at_inner) break;
+            const int n_leaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(node < 0 && node != RT_BVH_DONE));
+            if (2 * n_leaf > __builtin_popcountll(at_inner) + n_leaf) break;
+            if (node >= 0) {
+                M_STAT(inner, true);
+                const NodeRegs b = load_node(sc.fbvh, node);
+                float tl, tr;
+                const bool hl = boxray_hit(m.br, b.lmin, b.lmax, m.tmin_f, m.tmax_f, tl);
+                const bool hr = boxray_hit(m.br, b.rmin, b.rmax, m.tmin_f, m.tmax_f, tr);
+                const int cl = b.left, cr = b.right;
+                if (hl && hr) { /* nearer child first */
+                    const bool left_first = tl <= tr;
+                    st.put(sp++, left_first ? cr : cl);
+                    node = left_first ? cl : cr;
+                } else if (hl) {
+                    node = cl;
+                } else if (hr) {
+                    node = cr;
+                } else {
+                    node = sp > 0 ? st.get(--sp) : RT_BVH_DONE;
+                }
             }
         }
-        if (node != RT_BVH_DONE) {
+        if (node < 0 && node != RT_BVH_DONE) {
             const int code = -1 - node;
             const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
             for (int r = r0; r < r1; ++r) {
+                M_STAT(leaf, true);
                 Real t;
                 if (fast_ref_hit<true>(sc, r, m.lo, m.ld, m.time, m.pass_lo, m.t, t, m.order)) {
                     m.t = t;
@@ -288,9 +319,15 @@ RT_DEV void m_run(const DScene& sc, const FVisit* visits, const int n_visits, ML
         m_tree_phase<ANYHIT>(sc, visits, m, st, RTR_MACHINE_WAIT);
         for (;;) {
             m_advance<ANYHIT>(sc, visits, n_visits, m);
-            if (m_phase(m) == M_FIN) client.finish(m);
+            if (m_phase(m) == M_FIN) {
+                M_STAT(fin, true);
+                client.finish(m);
+            }
             while (__builtin_amdgcn_ballot_w64(m_phase(m) == M_FETCH))
-                if (m_phase(m) == M_FETCH) client.fetch(m);
+                if (m_phase(m) == M_FETCH) {
+                    M_STAT(fetch, true);
+                    client.fetch(m);
+                }
             if (!__builtin_amdgcn_ballot_w64(m_phase(m) == M_ADV)) break;
         }
         if (!__builtin_amdgcn_ballot_w64(m_phase(m) != M_IDLE)) break;

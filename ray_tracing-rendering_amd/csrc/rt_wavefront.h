@@ -45,6 +45,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #define WF_NTYPES RTR_MAT_TYPE_COUNT
@@ -229,7 +231,77 @@ RT_DEV BlockWalk block_walk(WaveCursor* cursors, const WfState& S, int parity, b
 }
 
 /* ---- extend ------------------------------------------------------------------------------------------ */
-/* RICH = false: scenes lit by QuadLights only: no environment-light code on the miss branch */
+/* What the extend stage does with a slot before the cast: flush the finished sample into the pixel sum and
+ * start the next camera sample (renderer.h:73-79), or load the continued ray.  Returns false when the slot is
+ * (or has just become) WF_DONE. */
+RT_DEV bool wf_extend_load(const DScene& sc, const WfState& S, const RenderK& P, int slot, int& flags, V3& ro, V3& rd,
+                           Real& tm, uint32_t& rng) {
+    flags = S.flags[slot];
+    const int status = WF_STATUS(flags);
+    if (status == WF_DONE) return false;
+    if (status == WF_NEED_SAMPLE) {
+        int i, j, chunk;
+        bool active;
+        slot_pixel(P, slot, i, j, chunk, active);
+        V3 acc = ldv(S.ax, S.ay, S.az, slot);
+        if (!(flags & WF_FIRST)) acc = add(acc, ldv(S.lx, S.ly, S.lz, slot)); /* renderer.h:77-78 */
+        const int s = S.samp[slot] + 1;
+        S.samp[slot] = s;
+        const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+        if (s >= s_end) {
+            S.flags[slot] = WF_DONE;
+            double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
+            out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
+            return false;
+        }
+        stv(S.ax, S.ay, S.az, slot, acc);
+        rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
+        const Real u = (i + rng_next(rng)) / (P.W - 1);
+        const Real v = (j + rng_next(rng)) / (P.H - 1);
+        camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
+        stv(S.ox, S.oy, S.oz, slot, ro);
+        stv(S.dx, S.dy, S.dz, slot, rd);
+        S.tm[slot] = tm;
+        stv(S.tx, S.ty, S.tz, slot, mk(1.0, 1.0, 1.0));
+        stv(S.lx, S.ly, S.lz, slot, mk(0.0, 0.0, 0.0));
+        S.pdf[slot] = 0.0;
+        flags = 0; /* depth 0, not specular */
+        return true;
+    }
+    ro = ldv(S.ox, S.oy, S.oz, slot);
+    rd = ldv(S.dx, S.dy, S.dz, slot);
+    tm = S.tm[slot];
+    rng = S.rng[slot];
+    flags &= ~3;
+    return true;
+}
+/* ... and after it: the miss (mis_path_integrator.h:37-67, rr_path_integrator.h:31-33) or the 16-byte hit.
+ * `ref` < 0 and `med` < 0: nothing was hit.  RICH = false: scenes lit by QuadLights only, no environment-light
+ * code on the miss branch. */
+template <bool RICH>
+RT_DEV void wf_extend_store(const DScene& sc, const WfState& S, const RenderK& P, int slot, int flags, V3 ro, V3 rd, Real t,
+                            int ref, int inst, int med, uint32_t rng) {
+    if (ref < 0 && med < 0) {
+        const V3 thr = ldv(S.tx, S.ty, S.tz, slot);
+        V3 add_l;
+        if (RICH && P.integrator == RTR_INTEGRATOR_MIS)
+            add_l = miss_radiance<RTR_INTEGRATOR_MIS, RT_MS_FULL>(sc, thr, ro, rd, flags >> 8, (flags & WF_SPEC) != 0, S.pdf[slot]);
+        else if (RICH && P.integrator == RTR_INTEGRATOR_NEE)
+            add_l = miss_radiance<RTR_INTEGRATOR_NEE, RT_MS_FULL>(sc, thr, ro, rd, flags >> 8, (flags & WF_SPEC) != 0, 0.0);
+        else
+            add_l = mul(thr, ld3(sc.background));
+        stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), add_l));
+        S.flags[slot] = flags | WF_NEED_SAMPLE;
+    } else {
+        S.ht[slot] = t;
+        S.href[slot] = med >= 0 ? ~med : ref;
+        S.hinst[slot] = inst;
+        S.flags[slot] = flags | WF_HIT;
+    }
+    S.rng[slot] = rng;
+}
+
+/* persistent-threads form: the stage as a client of the traversal machine */
 template <bool RICH>
 struct ExtendClient {
     const DScene& sc;
@@ -246,76 +318,20 @@ struct ExtendClient {
             return;
         }
         if (slot < 0) return;
-        int flags = S.flags[slot];
-        const int status = WF_STATUS(flags);
-        bool dead = status == WF_DONE;
+        int flags;
         V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
         Real tm = 0;
         uint32_t rng = 1;
-        if (status == WF_NEED_SAMPLE) {
-            int i, j, chunk;
-            bool active;
-            slot_pixel(P, slot, i, j, chunk, active);
-            V3 acc = ldv(S.ax, S.ay, S.az, slot);
-            if (!(flags & WF_FIRST)) acc = add(acc, ldv(S.lx, S.ly, S.lz, slot)); /* renderer.h:77-78 */
-            const int s = S.samp[slot] + 1;
-            S.samp[slot] = s;
-            const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
-            if (s >= s_end) {
-                S.flags[slot] = WF_DONE;
-                double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);
-                out[0] = acc.x, out[RTR_BLOCK] = acc.y, out[2 * RTR_BLOCK] = acc.z;
-                dead = true;
-            } else {
-                stv(S.ax, S.ay, S.az, slot, acc);
-                rng = rtr_sample_seed_inline(P.seed, P.W, i, j, s);
-                const Real u = (i + rng_next(rng)) / (P.W - 1);
-                const Real v = (j + rng_next(rng)) / (P.H - 1);
-                camera_get_ray(sc.camera, u, v, rng, ro, rd, tm);
-                stv(S.ox, S.oy, S.oz, slot, ro);
-                stv(S.dx, S.dy, S.dz, slot, rd);
-                S.tm[slot] = tm;
-                stv(S.tx, S.ty, S.tz, slot, mk(1.0, 1.0, 1.0));
-                stv(S.lx, S.ly, S.lz, slot, mk(0.0, 0.0, 0.0));
-                S.pdf[slot] = 0.0;
-                flags = 0; /* depth 0, not specular */
-            }
-        } else if (!dead) {
-            ro = ldv(S.ox, S.oy, S.oz, slot);
-            rd = ldv(S.dx, S.dy, S.dz, slot);
-            tm = S.tm[slot];
-            rng = S.rng[slot];
-            flags &= ~3;
-        }
-        walk.count_done(dead);
-        if (dead) return; /* ask for another slot */
+        const bool live = wf_extend_load(sc, S, P, slot, flags, ro, rd, tm, rng);
+        walk.count_done(!live);
+        if (!live) return; /* ask for another slot */
         m.slot = slot;
         m.aux = flags;
         ++n_closest;
         m_begin(m, ro, rd, tm, RT_INF, rng);
     }
-
     RT_DEV void finish(MLane& m) {
-        const int slot = m.slot, flags = m.aux;
-        if (!m_any_hit(m)) { /* mis_path_integrator.h:37-67, rr_path_integrator.h:31-33 */
-            const V3 thr = ldv(S.tx, S.ty, S.tz, slot);
-            V3 add_l;
-            if (RICH && P.integrator == RTR_INTEGRATOR_MIS)
-                add_l = miss_radiance<RTR_INTEGRATOR_MIS, RT_MS_FULL>(sc, thr, m.o, m.d, flags >> 8, (flags & WF_SPEC) != 0,
-                                                                      S.pdf[slot]);
-            else if (RICH && P.integrator == RTR_INTEGRATOR_NEE)
-                add_l = miss_radiance<RTR_INTEGRATOR_NEE, RT_MS_FULL>(sc, thr, m.o, m.d, flags >> 8, (flags & WF_SPEC) != 0, 0.0);
-            else
-                add_l = mul(thr, ld3(sc.background));
-            stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), add_l));
-            S.flags[slot] = flags | WF_NEED_SAMPLE;
-        } else {
-            S.ht[slot] = m.best_t;
-            S.href[slot] = m.best_med >= 0 ? ~m.best_med : m.best_ref;
-            S.hinst[slot] = m.best_inst;
-            S.flags[slot] = flags | WF_HIT;
-        }
-        S.rng[slot] = m.rng;
+        wf_extend_store<RICH>(sc, S, P, m.slot, m.aux, m.o, m.d, m.best_t, m.best_ref, m.best_inst, m.best_med, m.rng);
         m_set_phase(m, M_FETCH);
     }
 };
@@ -387,6 +403,68 @@ __global__ void __launch_bounds__(RTR_BLOCK, RTR_WF_EXTEND_WAVES)
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[2], c);
 }
 
+/* ---- lockstep forms of the two casting stages ------------------------------------------------------------
+ * One lane = one slot of the block, the whole wave runs run_program() / trace_fast() together: every
+ * instance, step and primitive record comes through scalar loads, the non-tree part of a cast runs with all
+ * lanes.  (The machine above keeps the lanes of a wave busy inside box trees, but splits them between its
+ * two phases; which form is faster for a scene is measured, see DESIGN.md.) */
+template <int TRAV, bool RICH>
+__global__ void __launch_bounds__(RTR_BLOCK, 4)
+    wf_extend_ls(const DScene* __restrict__ scp, const WfState S, const RenderK P, const int parity) {
+    extern __shared__ int lds_stack[];
+    const DScene& sc = *scp;
+    const Stack st{lds_stack + threadIdx.x};
+    const int32_t* list = S.list[parity];
+    const int n_entries = (int)S.n_list[parity];
+    unsigned n_closest = 0;
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const int blk = list[e], slot = blk * RTR_BLOCK + threadIdx.x;
+        int flags;
+        V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
+        Real tm = 0;
+        uint32_t rng = 1;
+        const bool live = wf_extend_load(sc, S, P, slot, flags, ro, rd, tm, rng);
+        const int n_live = __syncthreads_count(live);
+        if (threadIdx.x == 0) S.block_live[blk] = n_live;
+        if (!live) continue;
+        ++n_closest;
+        Real t = RT_INF;
+        int ref = -1, inst = -1, med = -1;
+        if (TRAV == RT_TRAV_PROGRAM)
+            run_program<false>(sc, ro, rd, tm, 0.001, t, ref, inst, med, rng, st);
+        else
+            trace_fast<false, TRAV == RT_TRAV_FAST>(sc, 0, sc.n_finst, ro, rd, tm, 0.001, t, ref, inst, st, 0);
+        wf_extend_store<RICH>(sc, S, P, slot, flags, ro, rd, t, ref, inst, med, rng);
+    }
+    const unsigned long long c = wave_sum(n_closest);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[1], c);
+}
+
+template <int TRAV>
+__global__ void __launch_bounds__(RTR_BLOCK, 4)
+    wf_connect_ls(const DScene* __restrict__ scp, const WfState S, const RenderK P, const int parity) {
+    extern __shared__ int lds_stack[];
+    const DScene& sc = *scp;
+    const Stack st{lds_stack + threadIdx.x};
+    const int32_t* list = S.list[parity];
+    const int n_entries = (int)S.n_list[parity];
+    unsigned n_shadow = 0;
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const int slot = list[e] * RTR_BLOCK + threadIdx.x;
+        const int flags = S.flags[slot];
+        if (!(flags & WF_SHADOW)) continue;
+        S.flags[slot] = flags & ~WF_SHADOW;
+        ++n_shadow;
+        uint32_t rng = TRAV == RT_TRAV_PROGRAM ? S.rng[slot] : 1u;
+        const bool blocked = cast_shadow<TRAV>(sc, ldv(S.sox, S.soy, S.soz, slot), ldv(S.swx, S.swy, S.swz, slot),
+                                               S.stmax[slot], rng, st);
+        if (TRAV == RT_TRAV_PROGRAM) S.rng[slot] = rng;
+        if (!blocked) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
+    }
+    const unsigned long long c = wave_sum(n_shadow);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&P.stats[2], c);
+}
+
 /* ---- shade ----------------------------------------------------------------------------------------------- */
 /* the hit record of the reference, rebuilt from what wf_extend stored */
 template <bool UV_POSSIBLE>
@@ -432,6 +510,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, MS == RT_MS_LEAN ? 4 : 2)
     const int n_entries = (int)S.n_list[parity];
     __shared__ int key_count[WF_NTYPES];
     __shared__ short order[RTR_BLOCK];
+    /* one workgroup per list entry: the launch covers the longest possible list, surplus workgroups leave at once */
     for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
         const int slot0 = list[e] * RTR_BLOCK;
         int slot = slot0 + threadIdx.x;
@@ -601,10 +680,19 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
     const dim3 block(RTR_BLOCK);
     const dim3 grid_all((unsigned)S.n_blocks);
     const dim3 grid_cast((unsigned)std::max(1, std::min(S.n_blocks, plan.n_cus * RTR_WF_EXTEND_WAVES)));
-    const dim3 grid_shade((unsigned)std::max(1, std::min(S.n_blocks, plan.n_cus * 16)));
-    if ((rc = wf_lds_attr(wf_extend<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend<false>, plan.lds, err)) ||
-        (rc = wf_lds_attr(wf_connect<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_connect<false>, plan.lds, err)))
-        return rc;
+    int grid_mult = 16; /* workgroups per CU of the block-per-workgroup stages (each walks several blocks) */
+    if (const char* e = std::getenv("RTR_WF_GRID")) grid_mult = std::max(1, std::atoi(e)); /* tuning knob */
+    const uint32_t grid_cap = (uint32_t)plan.n_cus * (uint32_t)grid_mult;
+    dim3 grid_shade(std::min((uint32_t)S.n_blocks, grid_cap)); /* shrinks with the published live count */
+    if (plan.lds > 64 * 1024) /* deep box trees only: every casting kernel gets the attribute */
+        if ((rc = wf_lds_attr(wf_extend<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend<false>, plan.lds, err)) ||
+            (rc = wf_lds_attr(wf_connect<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_connect<false>, plan.lds, err)) ||
+            (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_FAST, true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_FAST, false>, plan.lds, err)) ||
+            (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_PROGRAM, true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_PROGRAM, false>, plan.lds, err)) ||
+            (rc = wf_lds_attr(wf_connect_ls<RT_TRAV_FAST>, plan.lds, err)) || (rc = wf_lds_attr(wf_connect_ls<RT_TRAV_PROGRAM>, plan.lds, err)))
+            return rc;
+    if (plan.lds > 160 * 1024) return wf_lds_attr(wf_extend<true>, plan.lds, err);
+    const bool rich = !(plan.lean || plan.quadlit);
     int n_launch = 0;
     *pool.h_live = (uint32_t)S.n_blocks;
     hipLaunchKernelGGL(wf_init, grid_all, block, 0, stream, S, P);
@@ -646,10 +734,26 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
     bool cancelled = false;
     for (;;) {
         for (int b = 0; b < batch; ++b, ++iter) {
-            if (plan.lean || plan.quadlit)
-                hipLaunchKernelGGL(wf_extend<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
-            else
-                hipLaunchKernelGGL(wf_extend<true>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+#define WF_EXTEND_LS(T)                                                                                      \
+    do {                                                                                                     \
+        if (rich)                                                                                            \
+            hipLaunchKernelGGL((wf_extend_ls<T, true>), grid_shade, block, plan.lds, stream, sc, S, P, par);  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((wf_extend_ls<T, false>), grid_shade, block, plan.lds, stream, sc, S, P, par); \
+    } while (0)
+            if (plan.machine) {
+                if (rich)
+                    hipLaunchKernelGGL(wf_extend<true>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+                else
+                    hipLaunchKernelGGL(wf_extend<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+            } else if (plan.trav == RT_TRAV_PROGRAM) {
+                WF_EXTEND_LS(RT_TRAV_PROGRAM);
+            } else if (plan.trav == RT_TRAV_FAST) {
+                WF_EXTEND_LS(RT_TRAV_FAST);
+            } else {
+                WF_EXTEND_LS(RT_TRAV_FLAT);
+            }
+#undef WF_EXTEND_LS
             ++n_launch;
             if (!split) {
                 WF_SHADE(0);
@@ -657,10 +761,18 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
                 WF_SHADE(1);
             }
             if (shadows) {
-                if (plan.media)
-                    hipLaunchKernelGGL(wf_connect<true>, grid_cast, block, plan.lds, stream, sc, S, P, par);
-                else
-                    hipLaunchKernelGGL(wf_connect<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+                if (plan.machine) {
+                    if (plan.media)
+                        hipLaunchKernelGGL(wf_connect<true>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+                    else
+                        hipLaunchKernelGGL(wf_connect<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
+                } else if (plan.trav == RT_TRAV_PROGRAM) {
+                    hipLaunchKernelGGL(wf_connect_ls<RT_TRAV_PROGRAM>, grid_shade, block, plan.lds, stream, sc, S, P, par);
+                } else if (plan.trav == RT_TRAV_FAST) {
+                    hipLaunchKernelGGL(wf_connect_ls<RT_TRAV_FAST>, grid_shade, block, plan.lds, stream, sc, S, P, par);
+                } else {
+                    hipLaunchKernelGGL(wf_connect_ls<RT_TRAV_FLAT>, grid_shade, block, plan.lds, stream, sc, S, P, par);
+                }
                 ++n_launch;
             }
             if (split) WF_SHADE(2);
@@ -673,7 +785,10 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
         ++n_batches;
         if (n_batches >= 2) { /* wait for the batch before the one just enqueued: the GPU still has a full batch queued */
             WF_HIP(hipEventSynchronize(pool.ev[n_batches & 1]));
-            if (__atomic_load_n(pool.h_live, __ATOMIC_ACQUIRE) == 0) break;
+            const uint32_t live = __atomic_load_n(pool.h_live, __ATOMIC_ACQUIRE);
+            if (live == 0) break;
+            /* blocks only die: the newest published count bounds every later list, so the launches shrink with it */
+            grid_shade = dim3(std::min(std::min(live, (uint32_t)S.n_blocks), grid_cap));
         }
         if (cancelled_upto && cancelled_upto->load() >= P.render_id) {
             cancelled = true;
@@ -684,6 +799,21 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
 #undef WF_SHADE_S
     hipLaunchKernelGGL(wf_finish, grid_all, block, 0, stream, S, P);
     ++n_launch;
+#ifdef RTR_MACHINE_STATS
+    {
+        (void)hipStreamSynchronize(stream);
+        MStats h{};
+        (void)hipMemcpyFromSymbol(&h, HIP_SYMBOL(g_mstats), sizeof h);
+        auto line = [](const char* n, unsigned long long t, unsigned long long l) {
+            std::fprintf(stderr, "  %-6s trips %.4g  lanes/trip %.1f\n", n, (double)t, t ? (double)l / t : 0.0);
+        };
+        std::fprintf(stderr, "[machine stats, extend + connect]\n");
+        line("tree", h.tree_trips, h.tree_lanes), line("inner", h.inner_trips, h.inner_lanes), line("leaf", h.leaf_trips, h.leaf_lanes);
+        line("adv", h.adv_trips, h.adv_lanes), line("fin", h.fin_trips, h.fin_lanes), line("fetch", h.fetch_trips, h.fetch_lanes);
+        MStats z{};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mstats), &z, sizeof z);
+    }
+#endif
     if (launches) *launches = n_launch;
     if (cancelled) return RTR_ERR_CANCELLED; /* unfinished pixels have no sum yet: the caller's buffer stays untouched */
     ResolveK R{P, d_rgb, (long long)row_stride};

@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -427,7 +428,9 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, b
 int auto_chunks(int pipeline, double resident_slots, int n_tiles, int spp) {
     int chunks = 1;
     if (pipeline == RTR_PIPELINE_WAVEFRONT) { /* one pool slot per pixel and chunk: keep the pool small */
-        while ((long long)n_tiles * chunks < 8192 && chunks * 2 * 16 <= spp && chunks < 64) chunks *= 2;
+        long long want_blocks = 8192;
+        if (const char* e = std::getenv("RTR_WF_BLOCKS")) want_blocks = std::atoll(e); /* tuning knob */
+        while ((long long)n_tiles * chunks < want_blocks && chunks * 2 * 8 <= spp && chunks < 64) chunks *= 2;
         return chunks; /* about 2 M slots (0.5 GB of path state) where the image allows it */
     }
     double best = 0;
@@ -821,6 +824,9 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
         plan.sort = !plan.lean && c->n_material_types > 1;
         plan.n_cus = c->n_cus;
         plan.lds = stack_bytes(c, trav);
+        plan.trav = trav;
+        plan.machine = false;
+        if (const char* e = std::getenv("RTR_WF_MACHINE")) plan.machine = std::atoi(e) != 0; /* tuning knob */
         rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), plan, P, p->integrator, d_rgb, row_stride,
                               c->stream, &c->cancelled_upto, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;

@@ -11,7 +11,7 @@
  * object list decides BVH topology: with the same scene seed the result flattens to the same
  * bytes as the reference's own graph (tests/test_host_scenes.py).
  */
-#include "rtr_scene_api.h"
+#include "rtr_renderer.h"
 
 #include <cstring>
 
@@ -213,5 +213,17 @@ int rtr_host_build_scene(int scene_id, uint32_t scene_seed, uint8_t** bytes, siz
 }
 
 void rtr_host_free(uint8_t* p) { std::free(p); }
+
+/* The output stage of the C++ host layer on a linear image (H rows of W pixels, row 0 = bottom row):
+ * RenderBuffer::store_linear_rows + to_rgb8 (host/rtr_renderer.h), i.e. what save_to_ppm writes.  `rgb8` receives
+ * W*H*3 bytes, top row first.  Lets the CPU tests pin the stage against the reference's own writer. */
+int rtr_host_output_stage(const double* linear, int width, int height, uint8_t* rgb8) {
+    if (!linear || !rgb8 || width <= 0 || height <= 0) return RTR_ERR_INVALID;
+    RenderBuffer buf(width, height);
+    buf.store_linear_rows(linear, 0, height, width);
+    const std::vector<unsigned char> out = buf.to_rgb8();
+    std::memcpy(rgb8, out.data(), out.size());
+    return RTR_OK;
+}
 
 } /* extern "C" */

@@ -30,20 +30,37 @@ class RenderBuffer {
     const std::vector<std::vector<color>>& get_data() const { return m_pixels; }
     int width() const { return m_width; }
     int height() const { return m_height; }
-    /* binary PPM with the bytes save_to_png encodes (render_buffer.h:39-51): Y flipped, uchar(c*255) */
-    bool save_to_ppm(const std::string& filename) const {
-        FILE* f = std::fopen(filename.c_str(), "wb");
-        if (!f) return false;
-        std::fprintf(f, "P6\n%d %d\n255\n", m_width, m_height);
+    /* write_color_to_buffer (renderer.h:126-140) for rows [y0, y1) of linear mean radiance (the device already
+     * applied scale = 1 / samples): sqrt gamma, clamp to [0, 1]; `lin` holds (y1 - y0) rows of `stride` pixels */
+    void store_linear_rows(const double* lin, int y0, int y1, int stride) {
+        for (int j = y0; j < y1; ++j)
+            for (int i = 0; i < m_width; ++i) {
+                const double* px = &lin[((size_t)(j - y0) * stride + i) * 3];
+                set_pixel(i, j, color(clamp(sqrt(px[0]), 0.0, 1.0), clamp(sqrt(px[1]), 0.0, 1.0), clamp(sqrt(px[2]), 0.0, 1.0)));
+            }
+    }
+    /* the bytes save_to_png hands to its encoder (render_buffer.h:36-51): Y flipped, uchar(c * 255) truncation */
+    std::vector<unsigned char> to_rgb8() const {
+        std::vector<unsigned char> out((size_t)m_width * m_height * 3);
         for (int j = 0; j < m_height; ++j)
             for (int i = 0; i < m_width; ++i) {
                 const color& p = m_pixels[m_height - 1 - j][i];
-                unsigned char px[3] = {(unsigned char)(p[0] * 255), (unsigned char)(p[1] * 255),
-                                       (unsigned char)(p[2] * 255)};
-                std::fwrite(px, 1, 3, f);
+                unsigned char* px = &out[((size_t)j * m_width + i) * 3];
+                px[0] = static_cast<unsigned char>(p[0] * 255);
+                px[1] = static_cast<unsigned char>(p[1] * 255);
+                px[2] = static_cast<unsigned char>(p[2] * 255);
             }
+        return out;
+    }
+    /* binary PPM of those bytes (the reference encodes them as PNG with stb_image_write: out of scope) */
+    bool save_to_ppm(const std::string& filename) const {
+        FILE* f = std::fopen(filename.c_str(), "wb");
+        if (!f) return false;
+        const std::vector<unsigned char> rgb = to_rgb8();
+        std::fprintf(f, "P6\n%d %d\n255\n", m_width, m_height);
+        const bool ok = std::fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
         std::fclose(f);
-        return true;
+        return ok;
     }
 
   private:
@@ -200,12 +217,7 @@ class Renderer {
             lin.assign((size_t)W * (y1 - y0) * 3, 0.0);
             rc = rtr_render_host(m_ctx, &p, lin.data(), W);
             if (rc) return m_error = rtr_last_error(m_ctx), rc;
-            for (int j = y0; j < y1; ++j)
-                for (int i = 0; i < W; ++i) { /* write_color_to_buffer, renderer.h:126-140 */
-                    const double* px = &lin[((size_t)(j - y0) * W + i) * 3];
-                    buf.set_pixel(i, j, color(clamp(sqrt(px[0]), 0.0, 1.0), clamp(sqrt(px[1]), 0.0, 1.0),
-                                              clamp(sqrt(px[2]), 0.0, 1.0)));
-                }
+            buf.store_linear_rows(lin.data(), y0, y1, W);
         }
         return RTR_OK;
     }

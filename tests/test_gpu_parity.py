@@ -646,6 +646,14 @@ def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr
         assert open(out_b, "rb").read() == raw
+    # end to end against the reference's own writer: the CLI's scene21 image at the golden configuration
+    # (bit-exact on this scene) must carry the pixels of the PNG the reference wrote from its own render
+    out_g = str(tmp_path / "cli_golden.ppm")
+    r = subprocess.run([cli, "21", "4", "--width", "64", "--spp", "16", "--seed", "1", "--out", out_g],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    want = np.fromfile(os.path.join(G.GOLD, "png_scene21_i4_64_spp16.rgb8"), dtype=np.uint8)
+    assert np.array_equal(np.frombuffer(open(out_g, "rb").read()[len(head):], dtype=np.uint8), want)
 
 
 def test_large_flat_list(ctx, rtr):
