@@ -53,6 +53,15 @@ def _render_or_unsupported(ctx, sc, params):
     return ctx.render(params)
 
 
+def _rows(mask, how):
+    """reduce a per-component boolean array to one value per record (empty arrays included)"""
+    mask = np.asarray(mask)
+    if mask.ndim == 1:
+        return mask
+    flat = mask.reshape(mask.shape[0], int(np.prod(mask.shape[1:])))
+    return flat.any(axis=1) if how == "any" else flat.all(axis=1)
+
+
 def _close(a, b, rtol):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -61,39 +70,50 @@ def _close(a, b, rtol):
 
 @pytest.mark.parametrize("sid", [21, 23, 9, 1, 8, 35])
 def test_unit_closest_hit(ctx, sid):
-    _upload(ctx, sid)
+    """Closest hit of whole scenes.  t / p / n / front_face / material involve only + - * / sqrt on the device
+    and in the reference, so they are BIT-EXACT on every scene -- except behind a constant_medium, whose free
+    path goes through log() (scenes 8, 9: the medium's own records and nothing else).  (u,v) of spheres come
+    from acos / atan2 (OCML here, glibc there): exact counts of records outside 1e-12 are recorded."""
+    sc = _upload(ctx, sid)
     gold = G.records("hits_scene%02d.bin" % sid, A.HIT_DTYPE)
     out = ctx.test_records("hits", gold)
     h = gold["hit"] == 1
-    if sid == 21:  # no libm on this path: everything bit-exact
-        assert np.array_equal(out["hit"], gold["hit"])
-        assert np.array_equal(out["rng_out"], gold["rng_out"])
-        for f in ("front_face", "material"):
-            assert np.array_equal(out[f][h], gold[f][h]), f
-        for f in ("t", "p", "n", "u", "v"):
-            assert np.array_equal(_bits(out[f][h]), _bits(gold[f][h])), f
-        return
-    same = out["hit"] == gold["hit"]
-    assert same.mean() >= 0.999, "hit flags differ on %d records" % (~same).sum()
-    assert (out["rng_out"] == gold["rng_out"]).mean() >= 0.999
-    both = h & (out["hit"] == 1) & (out["material"] == gold["material"])
-    assert both.sum() >= 0.999 * h.sum()
+    iso = np.flatnonzero(sc.materials["type"] == A.MAT_ISOTROPIC)
+    # a ray decided by a medium's random free path: log() of the draw
+    via_medium = np.isin(gold["material"], iso) | np.isin(out["material"], iso) | (out["rng_out"] != out["rng_in"])
+    exact = ~via_medium
+    assert np.array_equal(out["hit"][exact], gold["hit"][exact])
+    assert np.array_equal(out["rng_out"][exact], gold["rng_out"][exact])
+    he = h & exact
+    for f in ("front_face", "material"):
+        assert np.array_equal(out[f][he], gold[f][he]), f
+    tie_budget = 0
     for f in ("t", "p", "n"):
-        ok = _close(out[f][both], gold[f][both], 1e-12)
-        assert ok.mean() >= 0.999, f
+        bad = _rows(_bits(out[f][he]) != _bits(gold[f][he]), "any")
+        G.residue("hits%02d.%s.not_bit_exact" % (sid, f), int(bad.sum()), 0)
+    # rays that went through a medium: same decision and, where it matters, within the log() ulp
+    vm = via_medium
+    G.residue("hits%02d.medium.hit_flag_differs" % sid, int((out["hit"][vm] != gold["hit"][vm]).sum()), 2)
+    G.residue("hits%02d.medium.rng_differs" % sid, int((out["rng_out"][vm] != gold["rng_out"][vm]).sum()), 2)
+    bm = vm & h & (out["hit"] == 1) & (out["material"] == gold["material"])
+    for f in ("t", "p"):
+        ok = _rows(_close(out[f][bm], gold[f][bm], 1e-12), "all")
+        G.residue("hits%02d.medium.%s.outside_1e-12" % (sid, f), int((~ok).sum()), 2)
     # (u,v) only where the final primitive writes them: moving_sphere and constant_medium leave
     # whatever an earlier, farther hit of the same walk stored (hittable.h:10-17 is never reset),
     # which depends on visiting order inside compiled subtrees
-    sc = G.scene(sid)
-    no_uv_mats = set(np.flatnonzero(sc.materials["type"] == A.MAT_ISOTROPIC).tolist())
+    no_uv_mats = set(iso.tolist())
     no_uv_mats |= set(sc.nodes["a"][sc.nodes["type"] == A.NODE_MOVING_SPHERE].tolist())
+    both = h & (out["hit"] == 1) & (out["material"] == gold["material"])
     uv = both & ~np.isnan(gold["u"]) & ~np.isin(gold["material"], sorted(no_uv_mats))
-    # a ray through the coplanar side faces of two adjacent ground boxes ties exactly in t; the
-    # winner (in the reference: 1-ulp noise of its BVH box tests) only changes the face-relative
-    # (u,v): allow a few such records
-    for f in ("u", "v"):  # acos / atan2 from OCML
-        assert _close(out[f][uv], gold[f][uv], 1e-12).mean() >= 0.985, f
-    assert np.array_equal(out["front_face"][both], gold["front_face"][both])
+    # (a ray through the coplanar side faces of two adjacent ground boxes of scene 9 ties exactly in t; the winner
+    # -- in the reference: 1-ulp noise of its BVH box tests -- only changes the face-relative (u,v))
+    for f in ("u", "v"):
+        bits_differ = int((_bits(out[f][uv]) != _bits(gold[f][uv])).sum())
+        outside = int((~_close(out[f][uv], gold[f][uv], 1e-12)).sum())
+        G.residue("hits%02d.%s.not_bit_exact" % (sid, f), bits_differ, int(0.05 * uv.sum()) + 1 if sid != 21 else 0)
+        G.residue("hits%02d.%s.outside_1e-12" % (sid, f), outside, int(0.015 * uv.sum()) + 1 if sid != 21 else 0)
+    del tie_budget
 
 
 @pytest.mark.parametrize("sid", [23, 9, 35, 1011])
@@ -142,11 +162,18 @@ def test_li_records(ctx, sid, integ):
         assert np.array_equal(out["n_shadow"], gold["n_shadow"])
         assert np.array_equal(_bits(out["L"]), _bits(gold["L"]))
         return
-    same_path = (out["rng_exit"] == gold["rng_exit"]) & (out["n_closest"] == gold["n_closest"])
-    assert same_path.mean() >= 0.995, "%d of %d samples took another path" % ((~same_path).sum(), len(gold))
-    ok = np.all(_close(out["L"][same_path], gold["L"][same_path], 1e-9), axis=1)
-    assert ok.mean() >= 0.999
-    assert G.rel_l2(out["L"], gold["L"]) <= 5e-2  # a handful of diverged samples at most
+    # every sample whose path met no libm call is bit-exact; the others are counted
+    same_path = (out["rng_exit"] == gold["rng_exit"]) & (out["n_closest"] == gold["n_closest"]) & \
+                (out["n_shadow"] == gold["n_shadow"])
+    tag = "li%02d_i%d" % (sid, integ)
+    G.residue(tag + ".other_path", int((~same_path).sum()), int(0.005 * len(gold)))
+    bit_exact = np.all(_bits(out["L"]) == _bits(gold["L"]), axis=1)
+    G.residue(tag + ".L_not_bit_exact", int((~bit_exact).sum()), len(gold))
+    ok = np.all(_close(out["L"], gold["L"], 1e-9), axis=1)
+    G.residue(tag + ".L_outside_1e-9_same_path", int((~ok & same_path).sum()), int(0.001 * len(gold)) + 1)
+    rel = np.abs(out["L"][same_path] - gold["L"][same_path]) / np.maximum(np.abs(gold["L"][same_path]), 1e-300)
+    G.residue(tag + ".max_rel_err_same_path", float(rel.max()) if rel.size else 0.0, 1e-9)
+    G.residue(tag + ".rel_l2", G.rel_l2(out["L"], gold["L"]), 5e-2)
 
 
 IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_scene21_i4_64_spp16.f64",
@@ -405,8 +432,8 @@ def test_every_other_reference_scene(ctx, sid):
         st = ctx.stats()
         assert st["samples"] == info["width"] * info["height"] * info["spp"]
         close = np.all(_close(out, img, 1e-9) | (np.abs(out - img) <= 1e-12), axis=-1)
-        assert close.mean() >= 0.99, (pipe, close.mean())
-        assert G.rel_l2(out, img) <= 5e-2
+        G.residue("scene%02d.pipe%d.pixels_outside_1e-9" % (sid, pipe), int((~close).sum()), int(0.01 * close.size))
+        G.residue("scene%02d.pipe%d.rel_l2" % (sid, pipe), G.rel_l2(out, img), 5e-2)
 
 
 @pytest.mark.parametrize("sid", list(range(1001, 1011)))
