@@ -281,6 +281,11 @@ int rtr_render_device(rtr_context* ctx, const rtr_render_params* params,
 int rtr_render_host(rtr_context* ctx, const rtr_render_params* params,
                     double* h_rgb, int64_t row_stride);
 
+/* The number of partial sums per pixel the library would use for `params` (params->spp_chunks, or its own
+ * choice for 0: depends on the scene's kernel variant, the pipeline and the number of owned tiles).  Returns
+ * the count (>= 1) or a negative status.  Lets a caller render a crop with the summation of a full-size render. */
+int rtr_plan_chunks(rtr_context* ctx, const rtr_render_params* params);
+
 /* Wait for everything queued on the context stream. */
 int rtr_synchronize(rtr_context* ctx);
 

@@ -397,7 +397,7 @@ int set_lds(rtr_context* c, K kernel, size_t bytes) {
 }
 
 /* `dry`: only what can fail without touching the stream (the LDS size check / attribute, the occupancy query) */
-int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu = nullptr) {
+int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu) {
     MegaLaunch L{};
     /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
     L.trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
@@ -440,6 +440,19 @@ int auto_chunks(int pipeline, double resident_slots, int n_tiles, int spp) {
         if (eff > best) best = eff, chunks = cand;
     }
     return chunks;
+}
+
+int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu);
+
+/* spp_chunks = 0: the library's choice for this scene, pipeline and number of owned tiles */
+int choose_chunks(rtr_context* c, RenderK P, int integrator, int pipeline, int trav, int spp, int* chunks) {
+    /* workgroups of this kernel variant the chip holds at once (registers / LDS decide: 2-5 per CU) */
+    int per_cu = 4;
+    P.chunks = 1;
+    if (pipeline == RTR_PIPELINE_MEGAKERNEL)
+        if (int rc = launch_mega(c, P, integrator, trav, true, &per_cu)) return rc;
+    *chunks = auto_chunks(pipeline, (double)c->n_cus * (per_cu > 0 ? per_cu : 1), P.n_tiles, spp);
+    return RTR_OK;
 }
 
 int finish_stats(rtr_context* c) {
@@ -769,13 +782,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
         return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs the compiled traversals only: this graph (or "
                                             "RTR_FLAG_REFERENCE_ORDER) needs the reference-order walk of the megakernel");
     int chunks = p->spp_chunks;
-    if (chunks == 0) {
-        /* workgroups of this kernel variant the chip holds at once (registers / LDS decide: 2-5 per CU) */
-        int per_cu = 4;
-        P.chunks = 1;
-        if (pipeline == RTR_PIPELINE_MEGAKERNEL && (rc = launch_mega(c, P, p->integrator, trav, true, &per_cu))) return rc;
-        chunks = auto_chunks(pipeline, (double)c->n_cus * (per_cu > 0 ? per_cu : 1), P.n_tiles, p->spp);
-    }
+    if (chunks == 0 && (rc = choose_chunks(c, P, p->integrator, pipeline, trav, p->spp, &chunks))) return rc;
     P.chunks = chunks;
 
     /* A render that was queued without blocking may still be running.  Everything below is ordered behind
@@ -804,7 +811,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     P.cancel = static_cast<const uint32_t*>(c->b_cancel.p);
     P.partial = static_cast<double*>(c->b_partial.p);
     P.done = static_cast<int*>(c->b_done.p);
-    if (pipeline == RTR_PIPELINE_MEGAKERNEL && (rc = launch_mega(c, P, p->integrator, trav, true))) return rc;
+    if (pipeline == RTR_PIPELINE_MEGAKERNEL && (rc = launch_mega(c, P, p->integrator, trav, true, nullptr))) return rc;
 
     const uint32_t id = c->render_seq.fetch_add(1) + 1; /* rtr_cancel() from now on covers this render */
     P.render_id = id;
@@ -833,7 +840,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
         if (rc == RTR_ERR_CANCELLED) c->stats.cancelled = 1;
         c->stats.kernel_launches = launches;
     } else {
-        if ((rc = launch_mega(c, P, p->integrator, trav, false))) return rc;
+        if ((rc = launch_mega(c, P, p->integrator, trav, false, nullptr))) return rc;
         ResolveK R{P, d_rgb, (long long)row_stride};
         rtr_launch_resolve(R, c->stream);
         HIPCHK(c, hipGetLastError());
@@ -874,6 +881,22 @@ int rtr_render_host(rtr_context* c, const rtr_render_params* p, double* h_rgb, i
         if (e2 != hipSuccess) rc = fail(c, RTR_ERR_DEVICE, hipGetErrorString(e2));
     }
     return rc;
+}
+
+int rtr_plan_chunks(rtr_context* c, const rtr_render_params* p) {
+    if (!c) return RTR_ERR_INVALID;
+    if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_plan_chunks before rtr_upload_scene");
+    if (int prc = params_check(c, p)) return prc;
+    if (p->spp_chunks > 0) return p->spp_chunks;
+    HIPCHK(c, hipSetDevice(c->device));
+    RenderK P{};
+    rtr_render_params q = *p;
+    P.n_tiles = (int)owned_tiles(q, P.tiles_x, P.tiles_y).size();
+    if (P.n_tiles == 0) return 1;
+    const int pipeline = p->pipeline == RTR_PIPELINE_AUTO ? RTR_PIPELINE_MEGAKERNEL : p->pipeline;
+    int chunks = 1;
+    if (int rc = choose_chunks(c, P, p->integrator, pipeline, pick_trav(c, p->flags), p->spp, &chunks)) return rc;
+    return chunks;
 }
 
 int rtr_synchronize(rtr_context* c) {

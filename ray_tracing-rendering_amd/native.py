@@ -19,7 +19,7 @@ _STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR
 
 # every symbol include/rtr_hip.h and include/rtr_hip_test.h declare
 EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
-           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_synchronize", "rtr_cancel",
+           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_synchronize", "rtr_cancel",
            "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
            "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order")
 
@@ -64,6 +64,7 @@ def lib():
     L.rtr_upload_scene.argtypes = [vp, P(A.SceneDescC)]
     L.rtr_render_device.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64, C.c_int]
     L.rtr_render_host.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
+    L.rtr_plan_chunks.argtypes = [vp, P(A.RenderParamsC)]
     L.rtr_synchronize.argtypes = [vp]
     L.rtr_cancel.argtypes = [vp]
     L.rtr_get_stats.argtypes = [vp, P(A.RenderStatsC)]
@@ -159,6 +160,13 @@ class Context:
             raise ValueError("out must be a C-contiguous float64 array of shape (%d, %d, 3)" % (h, w))
         self._chk(self._L.rtr_render_host(self._h, C.byref(params), out.ctypes.data, w))
         return out
+
+    def plan_chunks(self, params):
+        """Partial sums per pixel the library would use for ``params`` (its own choice when spp_chunks = 0)."""
+        n = self._L.rtr_plan_chunks(self._h, C.byref(params))
+        if n < 0:
+            self._chk(n)
+        return n
 
     def synchronize(self):
         self._chk(self._L.rtr_synchronize(self._h))

@@ -634,6 +634,27 @@ def test_cancel_covers_queued_renders_only(ctx, rtr):
     assert not ctx.stats()["cancelled"]
 
 
+@pytest.mark.parametrize("workload", ["cornell_mis", "cornell_literal", "final_rr", "final_mis", "mis_spheres"])
+def test_full_spp_crop_of_every_baseline_config(ctx, rtr, workload):
+    """What is timed and shipped (spp_chunks = 0: the library's own partial sums) against the oracle at the
+    configuration's REAL spp: a 64x64 crop of the full-size image, the chunk count the full-size render picks.
+    Scenes 07 / 21 (no libm on the path): bit-exact with one running sum, <= 1e-13 with partial sums; the others
+    within the 1e-3 tolerance of BASELINE.json (measured: <= 1e-12).  Same check bench.py prints as `parity`."""
+    import bench
+    wl = dict(bench.WORKLOADS[workload])
+    sc = bench.load_scene(rtr, wl["scene"])
+    ctx.upload(sc)
+    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
+        probe = A.make_params(wl["W"], wl["H"], wl["spp"], integrator=wl["integ"], seed=1, spp_chunks=0, pipeline=pipe,
+                              region=(0, 0, wl["W"], wl["H"]))
+        chunks = ctx.plan_chunks(probe)
+        res = bench.crop_parity(rtr, ctx, sc, wl, chunks, pipe)
+        print(workload, pipe, res)
+        assert res["ok"], res
+        assert res["rel_l2_chunked_vs_chunks1"] <= 1e-13
+        G.residue("crop.%s.pipe%d.rel_l2_vs_oracle" % (workload, pipe), res["rel_l2_vs_oracle"], 1e-3)
+
+
 def test_large_image_shape_of_config_c5(ctx):
     """BASELINE C5 is 4096x4096 (65 536 tiles); at reduced spp the whole image path still holds:
     every pixel written, statistics complete, both pipelines agree bit for bit."""
