@@ -231,6 +231,10 @@ typedef struct rtr_render_params {
  * draws depend on that order; elsewhere both give the same image and this flag is a
  * cross-check. */
 #define RTR_FLAG_REFERENCE_ORDER 1
+/* Wavefront pipeline only: run the two ray-casting stages as PERSISTENT THREADS on the resumable traversal machine
+ * (every lane takes the next ray of its wave's blocks as soon as its own is finished) instead of lockstep waves.
+ * Same image bit for bit; measured slower on MI355X for every BASELINE scene, kept selectable. */
+#define RTR_FLAG_WF_PERSISTENT 2
 
 typedef struct rtr_render_stats {
     uint64_t samples;          /* camera samples finished                               */

@@ -25,6 +25,7 @@ LIGHT_QUAD, LIGHT_POINT, LIGHT_SPOT, LIGHT_DIRECTIONAL, LIGHT_ENV_UNIFORM, LIGHT
 INTEGRATOR_PATH, INTEGRATOR_RR, INTEGRATOR_PBR, INTEGRATOR_NEE, INTEGRATOR_MIS = 0, 1, 2, 3, 4
 PIPELINE_AUTO, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1, 2
 FLAG_REFERENCE_ORDER = 1
+FLAG_WF_PERSISTENT = 2
 
 NODE_DTYPE = np.dtype([("type", "<i4"), ("a", "<i4"), ("b", "<i4"), ("reserved", "<i4"), ("f", "<f8", (10,))])
 MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("tex", "<i4", (4,)), ("reserved", "<i4", (3,)), ("f", "<f8", (4,))])

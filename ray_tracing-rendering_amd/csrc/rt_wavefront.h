@@ -46,7 +46,6 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
-#include <cstdlib>
 #include <string>
 
 #define WF_NTYPES RTR_MAT_TYPE_COUNT
@@ -680,8 +679,10 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
     const dim3 block(RTR_BLOCK);
     const dim3 grid_all((unsigned)S.n_blocks);
     const dim3 grid_cast((unsigned)std::max(1, std::min(S.n_blocks, plan.n_cus * RTR_WF_EXTEND_WAVES)));
-    int grid_mult = 16; /* workgroups per CU of the block-per-workgroup stages (each walks several blocks) */
-    if (const char* e = std::getenv("RTR_WF_GRID")) grid_mult = std::max(1, std::atoi(e)); /* tuning knob */
+    /* workgroups per CU of the block-per-workgroup stages; each walks several blocks of the list.  Measured on
+     * MI355X: the flat Cornell stages are fastest with few, long-lived workgroups (4 per CU: 1 150 Msamples/s
+     * against 900 at 16 and 620 at 32), scenes with box trees with many (32 per CU) */
+    const int grid_mult = plan.trav == RT_TRAV_FLAT ? 4 : 32;
     const uint32_t grid_cap = (uint32_t)plan.n_cus * (uint32_t)grid_mult;
     dim3 grid_shade(std::min((uint32_t)S.n_blocks, grid_cap)); /* shrinks with the published live count */
     if (plan.lds > 64 * 1024) /* deep box trees only: every casting kernel gets the attribute */

@@ -12,7 +12,6 @@
 
 #include <atomic>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -346,7 +345,7 @@ int params_check(rtr_context* c, const rtr_render_params* p) {
     if (p->tile_stride > 1 && (p->tile_first < 0 || p->tile_first >= p->tile_stride))
         return fail(c, RTR_ERR_INVALID, "tile_first must be in [0, tile_stride)");
     if (p->spp_chunks < 0 || p->spp_chunks > p->spp) return fail(c, RTR_ERR_INVALID, "spp_chunks must be in [0, spp]");
-    if (p->flags & ~RTR_FLAG_REFERENCE_ORDER) return fail(c, RTR_ERR_INVALID, "unknown flag bits");
+    if (p->flags & ~(RTR_FLAG_REFERENCE_ORDER | RTR_FLAG_WF_PERSISTENT)) return fail(c, RTR_ERR_INVALID, "unknown flag bits");
     if (p->pipeline < RTR_PIPELINE_AUTO || p->pipeline > RTR_PIPELINE_WAVEFRONT)
         return fail(c, RTR_ERR_INVALID, "unknown pipeline");
     return RTR_OK;
@@ -428,9 +427,7 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, b
 int auto_chunks(int pipeline, double resident_slots, int n_tiles, int spp) {
     int chunks = 1;
     if (pipeline == RTR_PIPELINE_WAVEFRONT) { /* one pool slot per pixel and chunk: keep the pool small */
-        long long want_blocks = 8192;
-        if (const char* e = std::getenv("RTR_WF_BLOCKS")) want_blocks = std::atoll(e); /* tuning knob */
-        while ((long long)n_tiles * chunks < want_blocks && chunks * 2 * 8 <= spp && chunks < 64) chunks *= 2;
+        while ((long long)n_tiles * chunks < 8192 && chunks * 2 * 8 <= spp && chunks < 64) chunks *= 2;
         return chunks; /* about 2 M slots (0.5 GB of path state) where the image allows it */
     }
     double best = 0;
@@ -832,8 +829,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
         plan.n_cus = c->n_cus;
         plan.lds = stack_bytes(c, trav);
         plan.trav = trav;
-        plan.machine = false;
-        if (const char* e = std::getenv("RTR_WF_MACHINE")) plan.machine = std::atoi(e) != 0; /* tuning knob */
+        plan.machine = (p->flags & RTR_FLAG_WF_PERSISTENT) != 0;
         rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), plan, P, p->integrator, d_rgb, row_stride,
                               c->stream, &c->cancelled_upto, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;

@@ -226,4 +226,7 @@ int rtr_host_output_stage(const double* linear, int width, int height, uint8_t* 
     return RTR_OK;
 }
 
+/* tile bookkeeping of the multi-context Renderer (host/rtr_renderer.h), for the CPU tests */
+int rtr_host_tile_owner(int width, int height, int i, int j, int n_workers) { return rtr::tile_owner(width, height, i, j, n_workers); }
+
 } /* extern "C" */

@@ -18,6 +18,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstring>
+#include <thread>
 
 class RenderBuffer {
   public:
@@ -133,16 +135,48 @@ class DirectLightIntegrator : public Integrator { /* renderer/direct_light_integ
     int m_max_depth = 50, m_rr_start_depth = 3;
 };
 
+namespace rtr {
+/* 16x16 tiles in the reference's dispatch numbering (renderer.h:40-44,61-62): tile 0 is the top-left one */
+inline int tile_index_of_pixel(int W, int H, int i, int j) {
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    return ((tiles_y - 1) - j / 16) * tiles_x + i / 16;
+}
+/* which of `n` workers renders pixel (i, j): tiles are dealt round-robin, like index % tile_stride == tile_first
+ * of rtr_render_params */
+inline int tile_owner(int W, int H, int i, int j, int n) { return n > 1 ? tile_index_of_pixel(W, H, i, j) % n : 0; }
+} // namespace rtr
+
 class Renderer {
   public:
     struct Settings {
         int samples_per_pixel = 10;
     };
-    explicit Renderer(int device = 0) : m_is_rendering(false) {
-        m_status = rtr_create(device, &m_ctx);
-        if (m_status != RTR_OK) std::cerr << "rtr_create: " << rtr_last_error(nullptr) << "\n";
+    /* one GPU */
+    explicit Renderer(int device = 0) : Renderer(std::vector<int>{device}) {}
+    /* One context and one host thread per entry, like the reference's one worker per hardware thread
+     * (renderer.h:48-94): image tiles are dealt round-robin to the contexts (no exchange between them), each
+     * fills its tiles of the one RenderBuffer.  An ordinal may repeat (two contexts on one GPU). */
+    explicit Renderer(const std::vector<int>& devices) : m_is_rendering(false) {
+        for (int d : devices) {
+            rtr_context* c = nullptr;
+            const int rc = rtr_create(d, &c);
+            if (rc != RTR_OK) {
+                m_status = rc;
+                std::cerr << "rtr_create(" << d << "): " << rtr_last_error(nullptr) << "\n";
+                continue;
+            }
+            m_ctx.push_back(c);
+        }
     }
-    ~Renderer() { rtr_destroy(m_ctx); }
+    /* every GPU the process sees */
+    static std::vector<int> all_devices() {
+        std::vector<int> d;
+        for (int k = 0; k < rtr_device_count(); ++k) d.push_back(k);
+        return d;
+    }
+    ~Renderer() {
+        for (rtr_context* c : m_ctx) rtr_destroy(c);
+    }
     Renderer(const Renderer&) = delete;
     Renderer& operator=(const Renderer&) = delete;
 
@@ -161,12 +195,18 @@ class Renderer {
     void set_progress_bands(int n) { m_bands = n; }
     void cancel() {
         m_is_rendering = false;
-        if (m_ctx) rtr_cancel(m_ctx);
+        for (rtr_context* c : m_ctx) rtr_cancel(c);
     }
     bool is_rendering() const { return m_is_rendering; }
     int last_status() const { return m_status; }
-    const char* last_error() const { return rtr_last_error(m_ctx); }
+    const char* last_error() const { return m_error.c_str(); }
     double last_seconds() const { return m_seconds; }
+    int device_contexts() const { return (int)m_ctx.size(); }
+    /* The flattened scene stays on the GPUs between render() calls with the same world / camera / lights objects
+     * and background (the reference's scene graph is immutable once built); call this after changing a scene
+     * object in place. */
+    void invalidate_scene() { m_scene_key.clear(); }
+    int scene_uploads() const { return m_scene_uploads; }
 
     void render(shared_ptr<hittable> world, shared_ptr<camera> cam, const color& background,
                 RenderBuffer& target_buffer, const std::vector<shared_ptr<Light>>& lights = {}) {
@@ -184,13 +224,24 @@ class Renderer {
   private:
     int render_impl(const hittable& world, const camera& cam, const color& background, RenderBuffer& buf,
                     const std::vector<shared_ptr<Light>>& lights) {
-        if (!m_ctx) return m_error = rtr_last_error(nullptr), RTR_ERR_DEVICE;
+        if (m_ctx.empty()) return m_error = rtr_last_error(nullptr), RTR_ERR_DEVICE;
         if (!m_integrator) return m_error = "no integrator set", RTR_ERR_INVALID;
-        rtr_scene_storage st;
-        if (!rtr::flatten(world, lights, cam, background, st, m_error)) return RTR_ERR_UNSUPPORTED;
-        rtr_scene_desc d = st.desc();
-        int rc = rtr_upload_scene(m_ctx, &d);
-        if (rc) return m_error = rtr_last_error(m_ctx), rc;
+        const int n = (int)m_ctx.size();
+        /* flatten + upload once per scene, not once per render() call */
+        std::vector<const void*> key{&world, &cam};
+        for (const auto& l : lights) key.push_back(l.get());
+        std::vector<double> key_bg{background[0], background[1], background[2]};
+        if (key != m_scene_key || key_bg != m_scene_bg) {
+            rtr_scene_storage st;
+            if (!rtr::flatten(world, lights, cam, background, st, m_error)) return RTR_ERR_UNSUPPORTED;
+            rtr_scene_desc d = st.desc();
+            for (rtr_context* c : m_ctx) {
+                const int rc = rtr_upload_scene(c, &d);
+                if (rc) return m_scene_key.clear(), m_error = rtr_last_error(c), rc;
+            }
+            m_scene_key = key, m_scene_bg = key_bg;
+            ++m_scene_uploads;
+        }
         const int W = buf.width(), H = buf.height();
         rtr_render_params p{};
         p.image_width = W, p.image_height = H;
@@ -201,12 +252,12 @@ class Renderer {
         p.integrator = m_integrator->rtr_integrator_id();
         p.seed = m_seed;
         p.pipeline = RTR_PIPELINE_AUTO;
-        p.tile_first = 0, p.tile_stride = 1;
         p.spp_chunks = 0;
         int bands = m_bands > 0 ? m_bands : (H + 255) / 256;
         const int tile_rows = (H + 15) / 16;
         bands = std::max(1, std::min(bands, tile_rows));
-        std::vector<double> lin;
+        std::vector<std::vector<double>> lin(n);
+        std::vector<int> rcs(n, RTR_OK);
         for (int b = 0; b < bands; ++b) { /* row 0 of the buffer is the bottom row; the top band goes first */
             const int r1 = tile_rows - (int)((long long)b * tile_rows / bands);
             const int r0 = tile_rows - (int)((long long)(b + 1) * tile_rows / bands);
@@ -214,10 +265,28 @@ class Renderer {
             if (y0 >= y1) continue;
             if (!m_is_rendering) return m_error = "render cancelled", RTR_ERR_CANCELLED;
             p.y0 = y0, p.y1 = y1;
-            lin.assign((size_t)W * (y1 - y0) * 3, 0.0);
-            rc = rtr_render_host(m_ctx, &p, lin.data(), W);
-            if (rc) return m_error = rtr_last_error(m_ctx), rc;
-            buf.store_linear_rows(lin.data(), y0, y1, W);
+            auto work = [&](int k) { /* context k: tiles index % n == k of this band, into its own host buffer */
+                rtr_render_params q = p;
+                q.tile_first = k, q.tile_stride = n;
+                lin[k].assign((size_t)W * (y1 - y0) * 3, 0.0);
+                rcs[k] = rtr_render_host(m_ctx[k], &q, lin[k].data(), W);
+            };
+            if (n == 1) {
+                work(0);
+            } else {
+                std::vector<std::thread> th;
+                for (int k = 0; k < n; ++k) th.emplace_back(work, k);
+                for (auto& t : th) t.join();
+            }
+            for (int k = 0; k < n; ++k)
+                if (rcs[k]) return m_error = rtr_last_error(m_ctx[k]), rcs[k];
+            if (n > 1) /* every pixel from the context that owns its tile */
+                for (int j = y0; j < y1; ++j)
+                    for (int i = 0; i < W; ++i) {
+                        const int k = rtr::tile_owner(W, H, i, j, n);
+                        if (k) std::memcpy(&lin[0][((size_t)(j - y0) * W + i) * 3], &lin[k][((size_t)(j - y0) * W + i) * 3], 24);
+                    }
+            buf.store_linear_rows(lin[0].data(), y0, y1, W);
         }
         return RTR_OK;
     }
@@ -225,7 +294,10 @@ class Renderer {
     Settings m_settings;
     std::atomic<bool> m_is_rendering;
     std::shared_ptr<Integrator> m_integrator;
-    rtr_context* m_ctx = nullptr;
+    std::vector<rtr_context*> m_ctx;
+    std::vector<const void*> m_scene_key;
+    std::vector<double> m_scene_bg;
+    int m_scene_uploads = 0;
     int m_status = RTR_OK;
     uint32_t m_seed = 1;
     int m_bands = 0;

@@ -655,6 +655,21 @@ def test_full_spp_crop_of_every_baseline_config(ctx, rtr, workload):
         G.residue("crop.%s.pipe%d.rel_l2_vs_oracle" % (workload, pipe), res["rel_l2_vs_oracle"], 1e-3)
 
 
+@pytest.mark.parametrize("sid,integ", [(21, 4), (9, 1), (22, 4), (22, 3), (1, 1), (23, 4), (8, 1)])
+def test_wavefront_persistent_threads_equal_lockstep(ctx, sid, integ):
+    """The traversal machine (rt_machine.h: per-lane program position, lane refill from the wave's blocks) is a
+    re-scheduling of run_program() / trace_fast(): same image and same cast counts as the lockstep stages and
+    as the megakernel, on flat, box-tree and step-program scenes."""
+    _upload(ctx, sid)
+    ref = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=A.PIPELINE_MEGAKERNEL))
+    sr = ctx.stats()
+    for flags in (0, A.FLAG_WF_PERSISTENT):
+        out = ctx.render(A.make_params(96, 64, 6, integrator=integ, seed=21, pipeline=A.PIPELINE_WAVEFRONT, flags=flags))
+        st = ctx.stats()
+        assert np.array_equal(_bits(out), _bits(ref)), flags
+        assert (st["closest_segments"], st["shadow_segments"]) == (sr["closest_segments"], sr["shadow_segments"])
+
+
 def test_large_image_shape_of_config_c5(ctx):
     """BASELINE C5 is 4096x4096 (65 536 tiles); at reduced spp the whole image path still holds:
     every pixel written, statistics complete, both pipelines agree bit for bit."""
@@ -694,6 +709,14 @@ def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr
         assert open(out_b, "rb").read() == raw
+    # N contexts, one host thread each (here: two contexts on GPU 0), tiles dealt round-robin: same bytes; the
+    # flattened scene is uploaded once however often render() is called
+    out_n = str(tmp_path / "cli_two.ppm")
+    r = subprocess.run([cli, "21", "4", "--width", "64", "--spp", "4", "--seed", "3", "--devices", "0,0", "--repeat", "2",
+                        "--out", out_n], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert open(out_n, "rb").read() == raw
+    assert b"contexts: 2  scene uploads: 1" in r.stdout, r.stdout
     # end to end against the reference's own writer: the CLI's scene21 image at the golden configuration
     # (bit-exact on this scene) must carry the pixels of the PNG the reference wrote from its own render
     out_g = str(tmp_path / "cli_golden.ppm")

@@ -101,3 +101,21 @@ def test_two_rank_gloo_gather_is_bit_identical_to_one_rank():
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def test_cpp_renderer_tile_bookkeeping_matches_python():
+    """host/rtr_renderer.h (the N-context Renderer): which context owns a pixel == index % n of the reference's
+    tile numbering (renderer.h:61-62), the same partition render_sharded / bench.py use."""
+    import ctypes as C
+    import importlib
+    rtr = importlib.import_module("ray_tracing-rendering_amd")
+    lib = rtr.hostscene.lib()
+    lib.rtr_host_tile_owner.argtypes = [C.c_int] * 5
+    for (W, H) in ((64, 64), (70, 50), (800, 800), (33, 17)):
+        for n in (1, 2, 3, 8):
+            owner = np.array([[lib.rtr_host_tile_owner(W, H, i, j, n) for i in range(0, W, 5)] for j in range(0, H, 3)])
+            want = np.zeros_like(owner)
+            for r in range(n):
+                m = rtr.renderer.ownership_mask(W, H, r, n)[::3, ::5]
+                want[m] = r
+            assert np.array_equal(owner, want), (W, H, n)
