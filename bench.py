@@ -175,6 +175,9 @@ def roofline(name, pipe_name, counts, samples, closest, shadow, kernel_ms, n_gpu
         r["bound"] = "hbm"
         r["traffic"] = traffic
         r["kernel_ms"] = round(kernel_ms, 3)
+        if traffic is not None:
+            r["hbm_actual_GBs"] = round(traffic / t * 1e-9, 2)
+            r["traffic_over_algorithmic"] = round(traffic / (alg_bytes / n_gpus), 3)
         if pipe_name != "wavefront":
             r["note"] = "no committed VALU count for this kernel: algorithmic-bytes figure only (the megakernel is not HBM-bound)"
         return r

@@ -43,6 +43,13 @@ int rtr_test_li(rtr_context* ctx, const rtr_render_params* params, rtr_li_record
 /* Make rtr_test_hits (which takes no render params) use the reference-order traversal. */
 int rtr_test_reference_order(rtr_context* ctx, int on);
 
+/* Counter calibration for profiles/: stream `n_doubles` doubles through the access shape of the wavefront
+ * stages (one 8-byte word per lane, consecutive lanes consecutive words: out[i] = in[i] + 1), `repeat` times.
+ * The launch reads and writes exactly n_doubles * 8 bytes each per repetition, which is what rocprofv3's
+ * FETCH_SIZE / WRITE_SIZE of the same run are compared with (MI355X_MICROARCH.md, HBM: widths other than
+ * 16 bytes per lane are uncalibrated).  Returns RTR_OK or a negative status. */
+int rtr_test_stream8(rtr_context* ctx, int64_t n_doubles, int repeat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,4 +371,9 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_li(const DScene sc, const Re
     r.n_closest = (int)cnt.closest, r.n_shadow = (int)cnt.shadow;
     recs[k] = r;
 }
+/* rtr_test_stream8: 8 bytes per lane in, 8 bytes per lane out */
+__global__ void __launch_bounds__(RTR_BLOCK) k_stream8(const double* __restrict__ in, double* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * RTR_BLOCK)
+        out[i] = in[i] + 1.0;
+}
 #endif /* RTR_TU_CAPI */

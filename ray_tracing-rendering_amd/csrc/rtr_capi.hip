@@ -1041,6 +1041,22 @@ int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs,
     return test_end(c, recs, n, sizeof *recs);
 }
 
+int rtr_test_stream8(rtr_context* c, int64_t n_doubles, int repeat) {
+    if (!c || n_doubles <= 0 || repeat <= 0) return RTR_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = ensure(c, c->b_test, (size_t)n_doubles * 16);
+    if (rc) return rc;
+    double* in = static_cast<double*>(c->b_test.p);
+    double* out = in + n_doubles;
+    HIPCHK(c, hipMemsetAsync(in, 0, (size_t)n_doubles * 16, c->stream));
+    for (int r = 0; r < repeat; ++r)
+        hipLaunchKernelGGL(k_stream8, dim3((unsigned)(c->n_cus * 16)), dim3(RTR_BLOCK), 0, c->stream, in, out, (long long)n_doubles);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTR_OK;
+}
+
 int rtr_test_reference_order(rtr_context* c, int on) {
     if (!c) return RTR_ERR_INVALID;
     c->force_exact = on != 0;

@@ -21,7 +21,7 @@ _STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR
 EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
            "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_synchronize", "rtr_cancel",
            "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
-           "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order")
+           "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order", "rtr_test_stream8")
 
 
 class SceneInfoC(C.Structure):
@@ -77,6 +77,7 @@ def lib():
         getattr(L, name).argtypes = [vp, vp, C.c_int64]
     L.rtr_test_li.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
     L.rtr_test_reference_order.argtypes = [vp, C.c_int]
+    L.rtr_test_stream8.argtypes = [vp, C.c_int64, C.c_int]
     if L.rtr_abi_version() != A.RTR_ABI_VERSION:
         raise RtrError(A.RTR_ERR_INVALID, "librtr_hip.so ABI version mismatch")
     _LIB = L
@@ -184,6 +185,10 @@ class Context:
     def reference_order(self, on):
         """Force the reference-order traversal for rtr_test_hits (renders use params.flags)."""
         self._chk(self._L.rtr_test_reference_order(self._h, 1 if on else 0))
+
+    def stream8(self, n_doubles, repeat=1):
+        """Counter calibration: stream n_doubles doubles in and out, 8 bytes per lane (include/rtr_hip_test.h)."""
+        self._chk(self._L.rtr_test_stream8(self._h, int(n_doubles), int(repeat)))
 
     # device unit kernels over golden-vector records (include/rtr_hip_test.h)
     def test_records(self, kind, recs, params=None):

@@ -80,10 +80,54 @@ for i, name in enumerate(workloads):
         c["write_bytes"] = passes["write"][i]["c"]["WRITE_SIZE"] * 1024
         c["fetch_note"] = "FETCH_SIZE x 1024, not doubled (no 16-byte-per-lane streaming reads in this kernel)"
     counts.setdefault(name, {})[info[name]["pipeline"]] = c
+# ---- calibration of FETCH_SIZE / WRITE_SIZE on the 8-byte-per-lane stream (4 launches of 1 GiB in + 1 GiB out)
+calib = {}
+for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = os.path.join(out, "calib_%s.csv" % cn)
+    if os.path.exists(f):
+        tot = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_stream8" in r["Kernel_Name"] and r["Counter_Name"] == cn)
+        calib[cn] = {"counter_bytes": tot * 1024, "true_bytes": 4 * (1 << 30), "true_over_counter": 4 * (1 << 30) / (tot * 1024) if tot else None}
+# ---- the wavefront pipeline (one render per file)
+for w in ("cornell_mis", "final_rr"):
+    bj = os.path.join(out, "wf_%s_bench.json" % w)
+    if not os.path.exists(bj):
+        continue
+    ln = json.load(open(bj))
+    c = {"samples": round(ln["value"] * 1e6 * ln["ms_per_step"] * 1e-3), "kernel": "wf_extend_ls + wf_shade + wf_connect_ls + wf_compact"}
+    for cn, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
+        f = os.path.join(out, "wf_%s_%s.csv" % (w, cn))
+        if os.path.exists(f):
+            raw = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == cn and ("wf_" in r["Kernel_Name"] or "k_resolve" in r["Kernel_Name"])) * 1024
+            k = (calib.get(cn) or {}).get("true_over_counter") or 1.0
+            c[key + "_raw"] = raw
+            c[key] = raw * k
+    c["fetch_note"] = "counter x 1024 x the factor measured on an 8-byte-per-lane stream of known size (calibration below)"
+    f = os.path.join(out, "wf_%s_sq.csv" % w)
+    if os.path.exists(f):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            if "wf_" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"].split("(")[0][:40]][r["Counter_Name"]] += float(r["Counter_Value"])
+        c["stages"] = {k: {"insts_valu": v["SQ_INSTS_VALU"], "lane_util": v["SQ_THREAD_CYCLES_VALU"] / max(v["SQ_INSTS_VALU"], 1) / 64,
+                           "wait_frac": v["SQ_WAIT_ANY"] / max(v["SQ_WAVE_CYCLES"], 1)} for k, v in acc.items() if v["SQ_WAVE_CYCLES"] > 1e6}
+        c["insts_valu"] = sum(v["SQ_INSTS_VALU"] for v in acc.values())
+        c["thread_cycles_valu"] = sum(v["SQ_THREAD_CYCLES_VALU"] for v in acc.values())
+    counts.setdefault(w, {})["wavefront"] = c
+if calib:
+    counts["_calibration_8B_per_lane"] = calib
 json.dump(counts, open(os.path.join(out, "%s_counts.json" % tag), "w"), indent=1, sort_keys=True)
 with open(os.path.join(out, "%s_counts.txt" % tag), "w") as f:
+    for cn, v in calib.items():
+        f.write("calibration %s: counter %.4g bytes for %.4g true bytes (factor %.3f)\n" % (cn, v["counter_bytes"], v["true_bytes"], v["true_over_counter"] or 0))
     for name in workloads:
         for pipe, c in counts[name].items():
+            if pipe == "wavefront":
+                f.write("%s [wavefront] samples %.4g  HBM-side bytes per render: fetch %.4g write %.4g (%.1f B/sample)\n" % (
+                    name, c["samples"], c.get("fetch_bytes", 0), c.get("write_bytes", 0),
+                    (c.get("fetch_bytes", 0) + c.get("write_bytes", 0)) / c["samples"]))
+                for k, v in c.get("stages", {}).items():
+                    f.write("    %-40s VALU insts %.4g  lane_util %.1f%%  wait %.1f%%\n" % (k, v["insts_valu"], 100 * v["lane_util"], 100 * v["wait_frac"]))
+                continue
             lu = c["thread_cycles_valu"] / c["insts_valu"] / 64
             f.write("%s [%s] %s\n  samples %.4g  VALU insts/sample %.1f  lane_util %.1f%%  wait %.1f%%  issue %.1f%%  valu-active %.1f%%\n" % (
                 name, pipe, c["kernel"][:70], c["samples"], c["insts_valu"] / c["samples"], 100 * lu,

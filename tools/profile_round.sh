@@ -36,4 +36,23 @@ pass f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_IN
 pass f32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA || true
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
+# 4. the wavefront pipeline on the headline and on scene 9: kernel trace, SQ, FETCH, WRITE
+for w in cornell_mis final_rr; do
+  wfonce="--workload $w --extras none --pipeline wavefront --steps 1 --warmup 0 --no-cpu-baseline --no-parity"
+  rm -rf /tmp/ktw && rocprofv3 --kernel-trace --stats -d /tmp/ktw -o kt --output-format csv -- python3 $root/bench.py $wfonce > $out/wf_${w}_bench.json 2>/dev/null
+  cp $(find /tmp/ktw -name '*kernel_stats.csv' | head -1) $out/wf_${w}_kernel_stats.csv
+  for cn in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmcw && rocprofv3 --pmc $cn -d /tmp/pmcw -o pmc --output-format csv -- python3 $root/bench.py $wfonce > /dev/null 2>&1
+    cp $(find /tmp/pmcw -name '*counter_collection.csv' | head -1) $out/wf_${w}_$cn.csv
+  done
+  rm -rf /tmp/pmcw && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU -d /tmp/pmcw -o pmc --output-format csv -- python3 $root/bench.py $wfonce > /dev/null 2>&1
+  cp $(find /tmp/pmcw -name '*counter_collection.csv' | head -1) $out/wf_${w}_sq.csv
+  echo "wavefront passes $w done"
+done
+# 5. FETCH_SIZE / WRITE_SIZE calibration on a known 8-byte-per-lane stream (the wavefront stages' access shape)
+for cn in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/cal && rocprofv3 --pmc $cn -d /tmp/cal -o pmc --output-format csv -- python3 $root/tools/calibrate_stream.py > /dev/null 2>&1
+  cp $(find /tmp/cal -name '*counter_collection.csv' | head -1) $out/calib_$cn.csv
+done
+echo "calibration done"
 python3 $root/tools/pmc_counts.py $out $tag $wl
