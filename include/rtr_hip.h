@@ -1,5 +1,5 @@
 /*
- * rtr_hip.h -- C ABI of the MI355X (gfx950) wavefront path tracer.
+ * rtr_hip.h -- C ABI of the MI355X (gfx950) path tracer.
  *
  * This is the drop-in boundary for ONE hot path of JiGuang283/Ray_Tracing-Rendering:
  * the tile-threaded integrator loop behind
@@ -198,9 +198,11 @@ typedef struct rtr_scene_desc {
 #define RTR_INTEGRATOR_MIS 4  /* MISPathIntegrator     renderer/mis_path_integrator.h:25-150 */
 
 /* device pipeline selection */
-#define RTR_PIPELINE_AUTO 0
+#define RTR_PIPELINE_AUTO 0       /* the megakernel (the faster one on every measured scene: DESIGN.md 4.4) */
 #define RTR_PIPELINE_MEGAKERNEL 1 /* one lane per pixel, in-register bounce loop     */
-#define RTR_PIPELINE_WAVEFRONT 2  /* SoA path pool in HBM, extend/shade/connect stages */
+#define RTR_PIPELINE_WAVEFRONT 2  /* SoA path pool in HBM, extend/shade/connect stages over live-block lists; all five
+                                     integrators; compiled traversals only (RTR_ERR_UNSUPPORTED for graphs that need the
+                                     reference-order walk or with RTR_FLAG_REFERENCE_ORDER) */
 
 typedef struct rtr_render_params {
     int32_t image_width;  /* W of the full image (pixel (i,j), j=0 is the bottom row, renderer.h:69-74) */

@@ -1,10 +1,11 @@
-"""MI355X-native wavefront path tracer behind the reference's ``Renderer::render`` boundary.
+"""MI355X-native path tracer behind the reference's ``Renderer::render`` boundary.
 
 The directory name carries a hyphen (it mirrors the upstream repository name), so import it
 with ``importlib.import_module("ray_tracing-rendering_amd")``.
 
 Layout:
-  csrc/      hand-written HIP kernels (gfx950) + the C ABI of include/rtr_hip.h -> librtr_hip.so
+  csrc/      hand-written HIP kernels (gfx950: register-resident megakernel, wavefront stages) + the C ABI of
+             include/rtr_hip.h -> librtr_hip.so
   host/      C++ host layer mirroring the reference's scene-description API + flattening
   scene.py   flattened scene container / .rtrs files
   native.py  ctypes binding of librtr_hip.so (fails loudly when the library is missing)
