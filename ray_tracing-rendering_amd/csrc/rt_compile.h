@@ -37,6 +37,7 @@ namespace rtc {
 
 constexpr int kLinearMax = 12; /* instances with more references get a box tree */
 constexpr int kLeafMax = 4;
+constexpr int kGroupMax = 8; /* = the most references a leaf link can name (FBvh) */
 constexpr int kMaxInstances = 64;
 constexpr int kMaxTreeDepth = 56; /* bounds the per-lane LDS stack of the box-tree traversal */
 
@@ -62,6 +63,7 @@ struct PendingRef {
     std::vector<int> wrappers; /* outermost first, as met on the way down */
     Box local;
     int order; /* position of the primitive's LAST visit in the reference's walk (tie-breaks equal t) */
+    int group; /* primitives of one small hittable_list (a `box` = 6 rects) stay together in one tree leaf; -1: none */
 };
 
 struct Builder {
@@ -76,6 +78,7 @@ struct Builder {
     std::vector<std::vector<PendingRef>> pending; /* per instance */
     std::map<std::pair<int, std::vector<uint64_t>>, std::pair<int, int>> seen; /* -> (instance, slot) */
     int visit_counter = 0;
+    int current_group = -1, group_counter = 0;
     bool too_complex = false;
 
     static uint64_t bits(double v) {
@@ -140,9 +143,15 @@ struct Builder {
             walk(n.a);
             if (n.b != n.a) walk(n.b);
             break;
-        case RTR_NODE_LIST:
+        case RTR_NODE_LIST: {
+            /* a short list of primitives (geometry/box.h: 6 rects) is one object for the box tree */
+            bool small = n.b >= 2 && n.b <= kGroupMax && current_group < 0;
+            for (int k = 0; k < n.b && small; ++k) small = s->nodes[s->list_children[n.a + k]].type >= RTR_NODE_SPHERE;
+            if (small) current_group = group_counter++;
             for (int k = 0; k < n.b; ++k) walk(s->list_children[n.a + k]);
+            if (small) current_group = -1;
             break;
+        }
         case RTR_NODE_TRANSLATE:
         case RTR_NODE_ROTATE_Y:
             chain.push_back(ix), wrappers.push_back(ix);
@@ -190,7 +199,7 @@ struct Builder {
                 ii = it->second;
             }
             seen[sk] = {ii - inst_base, (int)pending[ii - inst_base].size()};
-            pending[ii - inst_base].push_back(PendingRef{ix, wrappers, prim_box(n), order});
+            pending[ii - inst_base].push_back(PendingRef{ix, wrappers, prim_box(n), order, current_group});
         }
         }
     }
@@ -225,16 +234,24 @@ struct Builder {
         return x * y + y * z + z * x;
     }
 
-    /* Box tree over refs[lo, hi) (indices local to the instance; `ref_base` makes them global):
-     * binned surface-area heuristic, median split of the widest centroid axis when the bins do not
-     * separate anything.  Returns the link of the subtree (see FBvh) and its box. */
-    int build_tree(std::vector<PendingRef>& refs, int lo, int hi, int ref_base, int depth, int& max_depth, Box& box) {
+    /* One unit of the tree build: a single reference, or the references of one small list (a box). */
+    struct Item {
+        Box box;
+        std::vector<int> members; /* indices into the instance's pending references */
+    };
+    /* Box tree over items[lo, hi); `ref_off` = references laid out before them (instance-local; `ref_base` makes
+     * it global).  Binned surface-area heuristic, median split of the widest centroid axis when the bins do not
+     * separate anything; an item is never split, so a box's six faces share one leaf and the tree above them
+     * separates whole boxes (no overlapping siblings, a third of the depth-first backtracking).  Returns the link of
+     * the subtree (see FBvh) and its box. */
+    int build_tree(std::vector<Item>& items, int lo, int hi, int ref_off, int ref_base, int depth, int& max_depth, Box& box) {
         box = Box();
-        for (int k = lo; k < hi; ++k) box.grow(refs[k].local);
+        int n_refs = 0;
+        for (int k = lo; k < hi; ++k) box.grow(items[k].box), n_refs += (int)items[k].members.size();
         const int n = hi - lo;
-        if (n <= kLeafMax) return -1 - (((ref_base + lo) << 3) | (n - 1));
+        if (n_refs <= kLeafMax || (n == 1 && n_refs <= kGroupMax)) return -1 - (((ref_base + ref_off) << 3) | (n_refs - 1));
         max_depth = std::max(max_depth, depth);
-        auto centre = [&](int k, int c) { return 0.5 * (refs[k].local.lo[c] + refs[k].local.hi[c]); };
+        auto centre = [&](int k, int c) { return 0.5 * (items[k].box.lo[c] + items[k].box.hi[c]); };
         Box cb;
         for (int k = lo; k < hi; ++k) {
             const double ctr[3] = {centre(k, 0), centre(k, 1), centre(k, 2)};
@@ -251,8 +268,8 @@ struct Builder {
                 int cnt[kBins] = {0};
                 for (int k = lo; k < hi; ++k) {
                     const int b = std::min(kBins - 1, (int)(kBins * ((centre(k, axis) - c0) / ext)));
-                    bb[b].grow(refs[k].local);
-                    ++cnt[b];
+                    bb[b].grow(items[k].box);
+                    cnt[b] += (int)items[k].members.size();
                 }
                 Box right_box[kBins];
                 int right_cnt[kBins];
@@ -276,26 +293,28 @@ struct Builder {
         int mid;
         if (best_axis >= 0) {
             const double c0 = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
-            auto it = std::partition(refs.begin() + lo, refs.begin() + hi, [&](const PendingRef& r) {
-                const double ctr = 0.5 * (r.local.lo[best_axis] + r.local.hi[best_axis]);
+            auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& r) {
+                const double ctr = 0.5 * (r.box.lo[best_axis] + r.box.hi[best_axis]);
                 return std::min(kBins - 1, (int)(kBins * ((ctr - c0) / ext))) <= best_bin;
             });
-            mid = (int)(it - refs.begin());
+            mid = (int)(it - items.begin());
         } else {
             int axis = 0;
             for (int c = 1; c < 3; ++c)
                 if (cb.hi[c] - cb.lo[c] > cb.hi[axis] - cb.lo[axis]) axis = c;
             mid = (lo + hi) / 2;
-            std::nth_element(refs.begin() + lo, refs.begin() + mid, refs.begin() + hi,
-                             [axis](const PendingRef& x, const PendingRef& y) {
-                                 return x.local.lo[axis] + x.local.hi[axis] < y.local.lo[axis] + y.local.hi[axis];
+            std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                             [axis](const Item& x, const Item& y) {
+                                 return x.box.lo[axis] + x.box.hi[axis] < y.box.lo[axis] + y.box.hi[axis];
                              });
         }
+        int left_refs = 0;
+        for (int k = lo; k < mid; ++k) left_refs += (int)items[k].members.size();
         const int me = (int)out.bvh.size();
         out.bvh.push_back(FBvh{});
         Box bl, br;
-        const int l = build_tree(refs, lo, mid, ref_base, depth + 1, max_depth, bl);
-        const int r = build_tree(refs, mid, hi, ref_base, depth + 1, max_depth, br);
+        const int l = build_tree(items, lo, mid, ref_off, ref_base, depth + 1, max_depth, bl);
+        const int r = build_tree(items, mid, hi, ref_off + left_refs, ref_base, depth + 1, max_depth, br);
         FBvh node{};
         for (int c = 0; c < 3; ++c) {
             node.lmin[c] = float_down(bl.lo[c]), node.lmax[c] = float_up(bl.hi[c]);
@@ -329,7 +348,28 @@ struct Builder {
             if ((int)refs.size() > kLinearMax) {
                 int depth = 0;
                 Box all;
-                I.bvh_root = build_tree(refs, 0, (int)refs.size(), I.ref_first, 1, depth, all);
+                std::vector<Item> items;
+                std::map<int, int> item_of_group;
+                for (int k = 0; k < (int)refs.size(); ++k) {
+                    int it = -1;
+                    if (refs[k].group >= 0) {
+                        auto f = item_of_group.find(refs[k].group);
+                        if (f != item_of_group.end()) it = f->second;
+                    }
+                    if (it < 0) {
+                        it = (int)items.size();
+                        items.emplace_back();
+                        if (refs[k].group >= 0) item_of_group[refs[k].group] = it;
+                    }
+                    items[it].box.grow(refs[k].local);
+                    items[it].members.push_back(k);
+                }
+                I.bvh_root = build_tree(items, 0, (int)items.size(), 0, I.ref_first, 1, depth, all);
+                std::vector<PendingRef> ordered; /* references in leaf order; a group keeps the reference's visiting order */
+                ordered.reserve(refs.size());
+                for (const Item& it : items)
+                    for (int k : it.members) ordered.push_back(refs[k]);
+                refs.swap(ordered);
                 double bound = 0;
                 for (int c = 0; c < 3; ++c) bound = std::max(bound, std::max(std::fabs(all.lo[c]), std::fabs(all.hi[c])));
                 I.bound = float_up(bound);
