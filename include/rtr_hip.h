@@ -292,6 +292,13 @@ int rtr_render_host(rtr_context* ctx, const rtr_render_params* params,
  * the count (>= 1) or a negative status.  Lets a caller render a crop with the summation of a full-size render. */
 int rtr_plan_chunks(rtr_context* ctx, const rtr_render_params* params);
 
+/* Per-ray entry: `Integrator::Li(r, world, background, lights)` (renderer/integrator.h:12-19) for `n` camera
+ * samples of the uploaded scene, one GPU lane each.  Sample k is (pixel i = ijs[3k], j = ijs[3k+1], sample index
+ * s = ijs[3k+2]) of the image params describe: its ray is camera::get_ray under rtr_sample_seed(seed, W, i, j, s)
+ * exactly as in a render, and L[3k..3k+2] receives its radiance (not divided by spp).  params->integrator,
+ * max_depth, rr_start_depth and flags apply; region, tiles, chunks and pipeline do not.  Host arrays; blocking. */
+int rtr_li_samples(rtr_context* ctx, const rtr_render_params* params, const int32_t* ijs, double* L, int64_t n);
+
 /* Wait for everything queued on the context stream. */
 int rtr_synchronize(rtr_context* ctx);
 

@@ -1057,6 +1057,25 @@ int rtr_test_stream8(rtr_context* c, int64_t n_doubles, int repeat) {
     return RTR_OK;
 }
 
+int rtr_li_samples(rtr_context* c, const rtr_render_params* p, const int32_t* ijs, double* L, int64_t n) {
+    if (!c) return RTR_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!ijs || !L))) return fail(c, RTR_ERR_INVALID, "bad sample / radiance arrays");
+    if (int prc = params_check(c, p)) return prc;
+    std::vector<rtr_li_record> recs((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        rtr_li_record r{};
+        r.i = ijs[3 * k], r.j = ijs[3 * k + 1], r.s = ijs[3 * k + 2];
+        if (r.i < 0 || r.i >= p->image_width || r.j < 0 || r.j >= p->image_height || r.s < 0)
+            return fail(c, RTR_ERR_INVALID, "sample outside the image");
+        recs[(size_t)k] = r;
+    }
+    int rc = rtr_test_li(c, p, recs.data(), n); /* the same unit kernel the parity tests drive */
+    if (rc) return rc;
+    for (int64_t k = 0; k < n; ++k)
+        for (int q = 0; q < 3; ++q) L[3 * k + q] = recs[(size_t)k].L[q];
+    return RTR_OK;
+}
+
 int rtr_test_reference_order(rtr_context* c, int on) {
     if (!c) return RTR_ERR_INVALID;
     c->force_exact = on != 0;

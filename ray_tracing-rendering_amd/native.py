@@ -19,7 +19,7 @@ _STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR
 
 # every symbol include/rtr_hip.h and include/rtr_hip_test.h declare
 EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
-           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_synchronize", "rtr_cancel",
+           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_synchronize", "rtr_cancel",
            "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
            "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order", "rtr_test_stream8")
 
@@ -65,6 +65,7 @@ def lib():
     L.rtr_render_device.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64, C.c_int]
     L.rtr_render_host.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
     L.rtr_plan_chunks.argtypes = [vp, P(A.RenderParamsC)]
+    L.rtr_li_samples.argtypes = [vp, P(A.RenderParamsC), vp, vp, C.c_int64]
     L.rtr_synchronize.argtypes = [vp]
     L.rtr_cancel.argtypes = [vp]
     L.rtr_get_stats.argtypes = [vp, P(A.RenderStatsC)]
@@ -168,6 +169,14 @@ class Context:
         if n < 0:
             self._chk(n)
         return n
+
+    def li_samples(self, params, ijs):
+        """``Integrator::Li`` of the camera samples ``ijs`` ((n, 3) int32: pixel i, pixel j, sample index):
+        radiance (n, 3), not divided by spp."""
+        ijs = np.ascontiguousarray(ijs, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros((len(ijs), 3), dtype=np.float64)
+        self._chk(self._L.rtr_li_samples(self._h, C.byref(params), ijs.ctypes.data, out.ctypes.data, len(ijs)))
+        return out
 
     def synchronize(self):
         self._chk(self._L.rtr_synchronize(self._h))

@@ -176,6 +176,28 @@ def test_li_records(ctx, sid, integ):
     G.residue(tag + ".rel_l2", G.rel_l2(out["L"], gold["L"]), 5e-2)
 
 
+def test_per_ray_entry_of_the_main_abi(ctx):
+    """rtr_li_samples (include/rtr_hip.h): Integrator::Li per camera sample, the per-ray entry of the boundary
+    (renderer/integrator.h:12-19) -- against the reference's per-sample records and against a render."""
+    _upload(ctx, 21)
+    name = "li_scene21_i4.bin"
+    info = G.MANIFEST["files"][name]
+    gold = G.records(name, A.LI_DTYPE)
+    p = A.make_params(info["info"]["width"], info["info"]["height"], info["spp"], integrator=4, seed=info["seed"])
+    ijs = np.stack([gold["i"], gold["j"], gold["s"]], axis=1)
+    L = ctx.li_samples(p, ijs)
+    assert np.array_equal(_bits(L), _bits(gold["L"]))
+    # mean of a pixel's samples == the pixel of a render (one running sum, renderer.h:72-79)
+    img = ctx.render(A.make_params(p.image_width, p.image_height, 4, integrator=4, seed=info["seed"], spp_chunks=1))
+    i, j = 17, 23
+    acc = np.zeros(3)
+    for row in ctx.li_samples(p, [[i, j, s] for s in range(4)]):
+        acc = acc + row
+    assert np.array_equal(_bits((1.0 / 4) * acc), _bits(img[j, i]))
+    with pytest.raises(G.rtr.RtrError):
+        ctx.li_samples(p, [[p.image_width, 0, 0]])
+
+
 IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_scene21_i4_64_spp16.f64",
              "img_scene23_i4_64_spp16.f64", "img_scene09_i1_64_spp16.f64", "img_scene22_i4_64_spp16.f64",
              "img_scene21_i4_128_spp32.f64", "img_scene01_i1_64_spp16.f64", "img_scene08_i1_64_spp16.f64",
