@@ -140,10 +140,11 @@ def crop_parity(pkg, ctx, scene, wl, chunks_used, pipeline):
         return A.make_params(W, H, spp, integrator=wl["integ"], seed=1, region=region, pipeline=pipeline,
                              spp_chunks=chunks)
     ref, _ = G.oracle_render(scene, params(1), threads=os.cpu_count() or 1)
-    timed = ctx.render(params(chunks_used))   # the summation the timed render used
+    timed = ctx.render(params(0))             # spp_chunks = 0: the library's own partial sums, as in the timed render
+    crop_chunks = ctx.stats()["spp_chunks"]
     seq = ctx.render(params(1))               # one running sum per pixel, like renderer.h:72-79
     out = {"crop": list(region), "spp": spp, "samples": 64 * 64 * spp,
-           "rel_l2_vs_oracle": G.rel_l2(timed, ref), "spp_chunks": chunks_used,
+           "rel_l2_vs_oracle": G.rel_l2(timed, ref), "spp_chunks": crop_chunks, "spp_chunks_of_the_timed_render": chunks_used,
            "rel_l2_chunks1_vs_oracle": G.rel_l2(seq, ref), "bit_exact_chunks1": bool(np.array_equal(seq, ref)),
            "rel_l2_chunked_vs_chunks1": G.rel_l2(timed, seq),
            "rmse_gamma_vs_oracle": float(np.sqrt(np.mean((np.clip(np.sqrt(timed), 0, 1) -

@@ -67,13 +67,16 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
     const DScene& sc = *scp;
     const Stack st{lds_stack + threadIdx.x};
     const Park pk{reinterpret_cast<double*>(lds_stack + stack_words * RTR_BLOCK) + threadIdx.x};
-    const int slot = blockIdx.x / P.chunks, chunk = blockIdx.x % P.chunks;
+    int slot, chunk;
+    mega_work(P, blockIdx.x, slot, chunk);
+    const int cell = slot * P.chunks + chunk; /* partial sum / completion word of this (tile, chunk) */
     int i, j;
     bool active;
     tile_pixel(P, slot, threadIdx.x, i, j, active);
     /* samples [s, s_end) of this pixel belong to this chunk */
-    int s = (int)((long long)chunk * P.spp / P.chunks);
-    const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+    int s, s_end_;
+    chunk_range(P, chunk, s, s_end_);
+    const int s_end = s_end_;
     pk.set3(PK_ACC, mk(0, 0, 0));
     PathCounters cnt;
     cnt.closest = 0, cnt.shadow = 0;
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
 #endif
     }
     const V3 acc = pk.get3(PK_ACC);
-    double* out = P.partial + (size_t)blockIdx.x * 3 * RTR_BLOCK + threadIdx.x;
+    double* out = P.partial + (size_t)cell * 3 * RTR_BLOCK + threadIdx.x;
     out[0] = acc.x;
     out[RTR_BLOCK] = acc.y;
     out[2 * RTR_BLOCK] = acc.z;
@@ -236,7 +239,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
      * (renderer.h:52-59): k_resolve stores a tile only when all its chunks ran to the end */
     const int interrupted = __syncthreads_or(active && s < s_end);
     if (threadIdx.x == 0) {
-        P.done[blockIdx.x] = !interrupted;
+        P.done[cell] = !interrupted;
         if (interrupted) atomicAdd(&P.stats[7], 1ull);
     }
 }

@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_init(const WfState S, const Rend
     int i, j, chunk;
     bool active;
     slot_pixel(P, slot, i, j, chunk, active);
-    const int s0 = (int)((long long)chunk * P.spp / P.chunks);
-    const int s1 = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+    int s0, s1;
+    chunk_range(P, chunk, s0, s1);
     active = active && s0 < s1;
     S.ax[slot] = 0, S.ay[slot] = 0, S.az[slot] = 0;
     S.lx[slot] = 0, S.ly[slot] = 0, S.lz[slot] = 0;
@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(RTR_BLOCK) wf_finish(const WfState S, const Re
     int i, j, chunk;
     bool active;
     slot_pixel(P, slot, i, j, chunk, active);
-    const int s0 = (int)((long long)chunk * P.spp / P.chunks);
+    int s0, s1;
+    chunk_range(P, chunk, s0, s1);
     unsigned long long a = 0;
     if (active) a = (unsigned long long)(S.samp[slot] - s0); /* samp ends at s_end: finished samples */
     a = wave_sum(a);
@@ -246,7 +247,8 @@ RT_DEV bool wf_extend_load(const DScene& sc, const WfState& S, const RenderK& P,
         if (!(flags & WF_FIRST)) acc = add(acc, ldv(S.lx, S.ly, S.lz, slot)); /* renderer.h:77-78 */
         const int s = S.samp[slot] + 1;
         S.samp[slot] = s;
-        const int s_end = (int)((long long)(chunk + 1) * P.spp / P.chunks);
+        int s_begin, s_end;
+        chunk_range(P, chunk, s_begin, s_end);
         if (s >= s_end) {
             S.flags[slot] = WF_DONE;
             double* out = P.partial + (size_t)(slot / RTR_BLOCK) * 3 * RTR_BLOCK + (slot % RTR_BLOCK);

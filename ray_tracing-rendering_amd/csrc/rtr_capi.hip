@@ -442,13 +442,33 @@ int auto_chunks(int pipeline, double resident_slots, int n_tiles, int spp) {
 int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu);
 
 /* spp_chunks = 0: the library's choice for this scene, pipeline and number of owned tiles */
-int choose_chunks(rtr_context* c, RenderK P, int integrator, int pipeline, int trav, int spp, int* chunks) {
+int choose_chunks(rtr_context* c, RenderK P, int integrator, int pipeline, int trav, int spp, int* chunks, int* guided) {
     /* workgroups of this kernel variant the chip holds at once (registers / LDS decide: 2-5 per CU) */
     int per_cu = 4;
     P.chunks = 1;
     if (pipeline == RTR_PIPELINE_MEGAKERNEL)
         if (int rc = launch_mega(c, P, integrator, trav, true, &per_cu)) return rc;
-    *chunks = auto_chunks(pipeline, (double)c->n_cus * (per_cu > 0 ? per_cu : 1), P.n_tiles, spp);
+    const double resident = (double)c->n_cus * (per_cu > 0 ? per_cu : 1);
+    *chunks = auto_chunks(pipeline, resident, P.n_tiles, spp);
+    /* Guided chunks.  With equal chunks a launch ends with part of the chip waiting for the last full-size
+     * workgroups -- a tenth of the time of a rank's eighth of C2 (313 tiles: 4.9 rounds over the resident slots).
+     * Instead three quarters of the chunks carry 90 % of a pixel's samples and run first; the rest is cut into thirds
+     * of that size and drains the launch.  Measured on one GPU, scene 21 800x800 spp 400, share of 1 / 2 / 4 / 8
+     * ranks: 75.2 / 38.6 / 20.3 / 10.9 ms with equal chunks, 74.5 / 37.9 / 19.8 / 10.2 ms guided (100 / 98 / 94 / 91 %
+     * of the ideal share).  Not worth it once the launch has tens of rounds anyway. */
+    guided[0] = guided[1] = guided[2] = 0;
+    const double rounds = (double)P.n_tiles * *chunks / resident;
+    if (pipeline == RTR_PIPELINE_MEGAKERNEL && *chunks >= 4 && rounds < 30.0 && spp >= 8 * *chunks) {
+        const int n_big = *chunks - *chunks / 4;
+        const int big = (int)((0.90 * spp + n_big - 1) / n_big);
+        const int rem = spp - n_big * big;
+        const int small = std::max(1, big / 3);
+        if (rem > 0) {
+            const int n_small = (rem + small - 1) / small;
+            guided[0] = n_big, guided[1] = big, guided[2] = small;
+            *chunks = n_big + n_small;
+        }
+    }
     return RTR_OK;
 }
 
@@ -778,8 +798,9 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     if (pipeline == RTR_PIPELINE_WAVEFRONT && (!c->machine_ok || (trav != RT_TRAV_FLAT && trav != RT_TRAV_FAST && trav != RT_TRAV_PROGRAM)))
         return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs the compiled traversals only: this graph (or "
                                             "RTR_FLAG_REFERENCE_ORDER) needs the reference-order walk of the megakernel");
-    int chunks = p->spp_chunks;
-    if (chunks == 0 && (rc = choose_chunks(c, P, p->integrator, pipeline, trav, p->spp, &chunks))) return rc;
+    int chunks = p->spp_chunks, guided[3] = {0, 0, 0};
+    if (chunks == 0 && (rc = choose_chunks(c, P, p->integrator, pipeline, trav, p->spp, &chunks, guided))) return rc;
+    P.n_big = guided[0], P.big_spp = guided[1], P.small_spp = guided[2];
     P.chunks = chunks;
 
     /* A render that was queued without blocking may still be running.  Everything below is ordered behind
@@ -890,8 +911,8 @@ int rtr_plan_chunks(rtr_context* c, const rtr_render_params* p) {
     P.n_tiles = (int)owned_tiles(q, P.tiles_x, P.tiles_y).size();
     if (P.n_tiles == 0) return 1;
     const int pipeline = p->pipeline == RTR_PIPELINE_AUTO ? RTR_PIPELINE_MEGAKERNEL : p->pipeline;
-    int chunks = 1;
-    if (int rc = choose_chunks(c, P, p->integrator, pipeline, pick_trav(c, p->flags), p->spp, &chunks)) return rc;
+    int chunks = 1, guided[3];
+    if (int rc = choose_chunks(c, P, p->integrator, pipeline, pick_trav(c, p->flags), p->spp, &chunks, guided)) return rc;
     return chunks;
 }
 

@@ -659,7 +659,7 @@ def test_cancel_covers_queued_renders_only(ctx, rtr):
 @pytest.mark.parametrize("workload", ["cornell_mis", "cornell_literal", "final_rr", "final_mis", "mis_spheres"])
 def test_full_spp_crop_of_every_baseline_config(ctx, rtr, workload):
     """What is timed and shipped (spp_chunks = 0: the library's own partial sums) against the oracle at the
-    configuration's REAL spp: a 64x64 crop of the full-size image, the chunk count the full-size render picks.
+    configuration's REAL spp: a 64x64 crop of the full-size image, partial sums chosen by the library (spp_chunks = 0).
     Scenes 07 / 21 (no libm on the path): bit-exact with one running sum, <= 1e-13 with partial sums; the others
     within the 1e-3 tolerance of BASELINE.json (measured: <= 1e-12).  Same check bench.py prints as `parity`."""
     import bench

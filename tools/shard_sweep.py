@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One rank's share of the headline render on ONE GPU (tile_stride = N, tile_first = 0): device time per chunk count,
+and what spp_chunks = 0 picks.  tools/shard_sweep.py [scene integ W H spp]"""
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+import bench
+
+pkg = importlib.import_module("ray_tracing-rendering_amd")
+A = pkg._abi
+scene, integ, W, H, spp = ([int(x) for x in sys.argv[1:6]] + [21, 4, 800, 800, 400][len(sys.argv) - 1:])[:5]
+sc = bench.load_scene(pkg, scene)
+with pkg.Context(0) as ctx:
+    ctx.upload(sc)
+    fb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    base = None
+    for n in (1, 2, 4, 8):
+        row = []
+        for chunks in (0, 4, 8, 16, 32, 64):
+            p = A.make_params(W, H, spp, integrator=integ, seed=1, tile_first=0, tile_stride=n, spp_chunks=chunks)
+            best = 1e9
+            for _ in range(3):
+                ctx.render_into(p, fb.data_ptr(), W, blocking=True)
+                best = min(best, ctx.stats()["device_ms"])
+            row.append((ctx.stats()["spp_chunks"], best))
+        if n == 1:
+            base = row[0][1]
+        print("N=%d  auto: %d chunks %.3f ms (%.1f%% of ideal)  | " % (n, row[0][0], row[0][1], 100 * base / n / row[0][1]) +
+              "  ".join("%d: %.3f" % r for r in row[1:]))
