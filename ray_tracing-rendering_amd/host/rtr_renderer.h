@@ -203,16 +203,20 @@ class Renderer {
     double last_seconds() const { return m_seconds; }
     int device_contexts() const { return (int)m_ctx.size(); }
     /* The flattened scene stays on the GPUs between render() calls with the same world / camera / lights objects
-     * and background (the reference's scene graph is immutable once built); call this after changing a scene
-     * object in place. */
-    void invalidate_scene() { m_scene_key.clear(); }
+     * and background (the reference's scene graph is immutable once built; the Renderer holds the objects, so an
+     * address cannot come back as another scene); call this after changing a scene object in place. */
+    void invalidate_scene() { m_scene_valid = false; }
     int scene_uploads() const { return m_scene_uploads; }
 
     void render(shared_ptr<hittable> world, shared_ptr<camera> cam, const color& background,
                 RenderBuffer& target_buffer, const std::vector<shared_ptr<Light>>& lights = {}) {
         m_is_rendering = true;
         const auto t0 = std::chrono::high_resolution_clock::now();
-        m_status = render_impl(*world, *cam, background, target_buffer, lights);
+        /* the cache below compares object identities: holding the objects keeps their addresses from being reused */
+        const bool same_scene = world == m_world && cam == m_cam && lights == m_lights &&
+                                background[0] == m_scene_bg[0] && background[1] == m_scene_bg[1] && background[2] == m_scene_bg[2];
+        m_status = render_impl(*world, *cam, background, target_buffer, lights, same_scene && m_scene_valid);
+        if (m_scene_valid) m_world = world, m_cam = cam, m_lights = lights;
         m_seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
         m_is_rendering = false;
         if (m_status == RTR_OK)
@@ -223,23 +227,22 @@ class Renderer {
 
   private:
     int render_impl(const hittable& world, const camera& cam, const color& background, RenderBuffer& buf,
-                    const std::vector<shared_ptr<Light>>& lights) {
+                    const std::vector<shared_ptr<Light>>& lights, bool scene_on_device) {
         if (m_ctx.empty()) return m_error = rtr_last_error(nullptr), RTR_ERR_DEVICE;
         if (!m_integrator) return m_error = "no integrator set", RTR_ERR_INVALID;
         const int n = (int)m_ctx.size();
         /* flatten + upload once per scene, not once per render() call */
-        std::vector<const void*> key{&world, &cam};
-        for (const auto& l : lights) key.push_back(l.get());
-        std::vector<double> key_bg{background[0], background[1], background[2]};
-        if (key != m_scene_key || key_bg != m_scene_bg) {
+        if (!scene_on_device) {
+            m_scene_valid = false;
             rtr_scene_storage st;
             if (!rtr::flatten(world, lights, cam, background, st, m_error)) return RTR_ERR_UNSUPPORTED;
             rtr_scene_desc d = st.desc();
             for (rtr_context* c : m_ctx) {
                 const int rc = rtr_upload_scene(c, &d);
-                if (rc) return m_scene_key.clear(), m_error = rtr_last_error(c), rc;
+                if (rc) return m_error = rtr_last_error(c), rc;
             }
-            m_scene_key = key, m_scene_bg = key_bg;
+            m_scene_bg[0] = background[0], m_scene_bg[1] = background[1], m_scene_bg[2] = background[2];
+            m_scene_valid = true;
             ++m_scene_uploads;
         }
         const int W = buf.width(), H = buf.height();
@@ -295,8 +298,11 @@ class Renderer {
     std::atomic<bool> m_is_rendering;
     std::shared_ptr<Integrator> m_integrator;
     std::vector<rtr_context*> m_ctx;
-    std::vector<const void*> m_scene_key;
-    std::vector<double> m_scene_bg;
+    shared_ptr<hittable> m_world; /* the scene whose flattened form is on the GPUs */
+    shared_ptr<camera> m_cam;
+    std::vector<shared_ptr<Light>> m_lights;
+    double m_scene_bg[3] = {0, 0, 0};
+    bool m_scene_valid = false;
     int m_scene_uploads = 0;
     int m_status = RTR_OK;
     uint32_t m_seed = 1;
