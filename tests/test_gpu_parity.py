@@ -692,6 +692,27 @@ def test_wavefront_persistent_threads_equal_lockstep(ctx, sid, integ):
         assert (st["closest_segments"], st["shadow_segments"]) == (sr["closest_segments"], sr["shadow_segments"])
 
 
+def test_headline_image_at_full_size_and_spp_is_bit_exact(ctx, rtr):
+    """BASELINE C2 itself, not a crop: all 640 000 pixels of the Cornell box 800x800 at spp 400 (MIS) from the
+    megakernel with one running sum per pixel == the CPU oracle, bit for bit (the oracle is bit-exact against
+    the reference's own renders of this scene); the shipped summation (spp_chunks = 0) within 1e-13.
+    About 25 s of oracle time on the GPU box's host cores."""
+    import os
+    import bench
+    wl = bench.WORKLOADS["cornell_mis"]
+    sc = bench.load_scene(rtr, wl["scene"])
+    ctx.upload(sc)
+    p1 = A.make_params(wl["W"], wl["H"], wl["spp"], integrator=wl["integ"], seed=1, spp_chunks=1)
+    ref, st = G.oracle_render(sc, p1, threads=os.cpu_count() or 1)
+    out = ctx.render(p1)
+    gs = ctx.stats()
+    assert (gs["samples"], gs["closest_segments"], gs["shadow_segments"]) == \
+        (st["samples"], st["closest_segments"], st["shadow_segments"])
+    assert np.array_equal(_bits(out), _bits(ref))
+    p0 = A.make_params(wl["W"], wl["H"], wl["spp"], integrator=wl["integ"], seed=1, spp_chunks=0)
+    G.residue("c2_full_image.chunked.rel_l2", G.rel_l2(ctx.render(p0), ref), 1e-13)
+
+
 def test_large_image_shape_of_config_c5(ctx):
     """BASELINE C5 is 4096x4096 (65 536 tiles); at reduced spp the whole image path still holds:
     every pixel written, statistics complete, both pipelines agree bit for bit."""
