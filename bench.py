@@ -43,6 +43,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this host driver needs dmabuf IPC (RCCL / sharing device memory across processes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector: 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz
