@@ -240,6 +240,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
+            # RCCL carries the barrier and the max-over-ranks reduction; the framebuffer gather is host-side (gloo)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             gloo = dist.new_group(backend="gloo")
         else:

@@ -271,7 +271,13 @@ void rtr_destroy(rtr_context* ctx);
 int rtr_set_stream(rtr_context* ctx, void* hip_stream);
 
 /* Validate + upload an immutable flattened scene.  Replaces the `world`, `cam`,
- * `background`, `lights` arguments of Renderer::render (renderer.h:30-32). */
+ * `background`, `lights` arguments of Renderer::render (renderer.h:30-32).
+ * Every record of every array is checked, reachable from `root` or not: indices and
+ * types in range, no cycle, image texels and environment tables inside image_bytes,
+ * perlin permutation entries in 0..255, and finite parameters for the primitives and
+ * transforms the graph reaches (RTR_ERR_INVALID / RTR_ERR_UNSUPPORTED with a message
+ * in rtr_last_error; nothing is uploaded then).  These checks are what keeps the host
+ * and the kernels inside the arrays they were given: a scene file is untrusted input. */
 int rtr_upload_scene(rtr_context* ctx, const rtr_scene_desc* scene);
 
 /* Render the region into a DEVICE buffer of doubles, 3 per pixel:

@@ -258,6 +258,11 @@ struct Builder {
             cb.grow(ctr);
         }
         constexpr int kBins = 16;
+        /* bin of a centroid; total for any input (an extent that overflowed to inf gives NaN: bin 0) */
+        auto bin_of = [](double ctr, double c0, double ext) {
+            const double f = kBins * ((ctr - c0) / ext);
+            return f >= 0 ? (f < kBins ? (int)f : kBins - 1) : 0;
+        };
         int best_axis = -1, best_bin = -1;
         double best_cost = INFINITY;
         if (depth < kMaxTreeDepth - 8) { /* deep, badly separable sets fall back to balanced median splits */
@@ -267,7 +272,7 @@ struct Builder {
                 Box bb[kBins];
                 int cnt[kBins] = {0};
                 for (int k = lo; k < hi; ++k) {
-                    const int b = std::min(kBins - 1, (int)(kBins * ((centre(k, axis) - c0) / ext)));
+                    const int b = bin_of(centre(k, axis), c0, ext);
                     bb[b].grow(items[k].box);
                     cnt[b] += (int)items[k].members.size();
                 }
@@ -295,7 +300,7 @@ struct Builder {
             const double c0 = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
             auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& r) {
                 const double ctr = 0.5 * (r.box.lo[best_axis] + r.box.hi[best_axis]);
-                return std::min(kBins - 1, (int)(kBins * ((ctr - c0) / ext))) <= best_bin;
+                return bin_of(ctr, c0, ext) <= best_bin;
             });
             mid = (int)(it - items.begin());
         } else {

@@ -200,11 +200,12 @@ struct Validator {
             Frame& f = stk.back();
             const rtr_node& n = s->nodes[f.node];
             if (f.next == 0) { /* first visit: check the record itself */
+                int n_geom = 0; /* leading f[] entries the scene compiler builds boxes from: must be finite */
                 switch (n.type) {
-                case RTR_NODE_BVH:
-                case RTR_NODE_TRANSLATE:
-                case RTR_NODE_ROTATE_Y:
+                case RTR_NODE_BVH: /* its box is only ever compared with a ray: any value is safe */
                 case RTR_NODE_FLIP_FACE: break;
+                case RTR_NODE_TRANSLATE: n_geom = 3; break;
+                case RTR_NODE_ROTATE_Y: n_geom = 2; break;
                 case RTR_NODE_LIST:
                     if (n.a < 0 || n.b < 0 || (int64_t)n.a + n.b > s->n_list_children)
                         return bad(RTR_ERR_INVALID, "hittable_list children out of range");
@@ -212,15 +213,16 @@ struct Validator {
                 case RTR_NODE_MEDIUM:
                     if (!material_ok(n.b)) return false;
                     break;
-                case RTR_NODE_SPHERE:
-                case RTR_NODE_MOVING_SPHERE:
+                case RTR_NODE_SPHERE: n_geom = 4; break;
+                case RTR_NODE_MOVING_SPHERE: n_geom = 9; break;
                 case RTR_NODE_XY_RECT:
                 case RTR_NODE_XZ_RECT:
-                case RTR_NODE_YZ_RECT:
-                    if (!material_ok(n.a)) return false;
-                    break;
+                case RTR_NODE_YZ_RECT: n_geom = 5; break;
                 default: return bad(RTR_ERR_UNSUPPORTED, "unknown hittable node type");
                 }
+                if (n.type >= RTR_NODE_SPHERE && !material_ok(n.a)) return false;
+                for (int k = 0; k < n_geom; ++k)
+                    if (!std::isfinite(n.f[k])) return bad(RTR_ERR_INVALID, "non-finite primitive or transform parameter");
             }
             const int m = child_count(n);
             if (f.next < m) {
@@ -299,6 +301,12 @@ struct Validator {
             if (!texture_ok(k, 0)) return code;
         for (int k = 0; k < s->n_materials; ++k)
             if (!material_ok(k)) return code;
+        /* materials/perlin.h:35 indexes ranvec[perm_x ^ perm_y ^ perm_z]: the device does the same, unchecked */
+        for (int k = 0; k < s->n_perlin; ++k)
+            for (int i = 0; i < 256; ++i)
+                if ((unsigned)s->perlin[k].perm_x[i] > 255u || (unsigned)s->perlin[k].perm_y[i] > 255u ||
+                    (unsigned)s->perlin[k].perm_z[i] > 255u)
+                    return (bad(RTR_ERR_INVALID, "perlin permutation entry out of range"), code);
         for (int k = 0; k < s->n_nodes; ++k) {
             const rtr_node& n = s->nodes[k];
             if (n.type < 0 || n.type >= RTR_NODE_TYPE_COUNT)

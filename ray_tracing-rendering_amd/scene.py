@@ -37,6 +37,8 @@ class Scene:
         buf = bytes(buf)
         if buf[:8] != _MAGIC:
             raise ValueError("not an RTRS0001 scene")
+        if len(buf) < 48:
+            raise ValueError("truncated scene file")
         h = struct.unpack_from("<8i", buf, 8)
         (nb,) = struct.unpack_from("<Q", buf, 40)
         off = 48

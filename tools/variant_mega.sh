@@ -12,4 +12,4 @@ grep -l "error" /tmp/variant_${name}_*.log | head -3 | xargs -r tail -5
 hipcc --offload-arch=gfx950 -shared -fPIC build/obj/capi.o build/obj/mega0_$name.o build/obj/mega1_$name.o build/obj/mega2_$name.o build/obj/wavefront.o \
   -o ray_tracing-rendering_amd/variants/librtr_hip_$name.so || exit 1
 cat /tmp/variant_${name}_*.log > /tmp/variant_$name.log
-python3 tools/kres.py /tmp/variant_$name.log | grep "k_megaILi1ELi3ELi1\|k_megaILi4ELi3ELi2" | sed "s/^/$name: /"
+python3 tools/kres.py /tmp/variant_$name.log | grep "k_megaILi1ELi3ELi1\|k_megaILi4ELi3ELi2\|k_megaILi4ELi4ELi0\|k_megaILi4ELi4ELi2" | sed "s/^/$name: /"
