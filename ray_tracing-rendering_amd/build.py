@@ -45,15 +45,25 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     from concurrent.futures import ThreadPoolExecutor
     out = os.path.join(HERE, "librtr_hip.so")
     sources = _sources(CSRC, (".hip", ".h"))
-    if not force and not extra_flags and not _newer(out, sources):
-        return out
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
+    # the flags the objects on disk were compiled with: a library left behind by an experiment
+    # (tools/build_hip.sh -DSOMETHING) is never mistaken for the product build
+    stamp = os.path.join(HERE, "librtr_hip.flags")  # next to the library: it travels with it
+    flags_now = " ".join(HIP_FLAGS + list(extra_flags))
+    try:
+        flags_then = open(stamp).read()
+    except OSError:
+        flags_then = None
+    if flags_then != flags_now:
+        force = True
+    if not force and not _newer(out, sources):
+        return out
 
     def compile_unit(unit):
         name, src, defs = unit
         obj = os.path.join(objdir, name + ".o")
-        if not force and not extra_flags and not _newer(obj, sources):
+        if not force and not _newer(obj, sources):
             return obj, ""
         cmd = [hipcc()] + HIP_FLAGS + list(extra_flags) + defs + ["-I" + INC, "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -66,6 +76,8 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     with ThreadPoolExecutor(max_workers=min(len(HIP_UNITS), os.cpu_count() or 1)) as pool:
         results = list(pool.map(compile_unit, HIP_UNITS))
     subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", out], check=True)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     if verbose:
         return out, "".join(log for _, log in results)
     return out
