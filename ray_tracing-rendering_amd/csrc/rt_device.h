@@ -323,16 +323,22 @@ RT_DEV void sphere_uv(V3 p, Real& u, Real& v) { /* geometry/sphere.h:24-30 */
 
 /* ---- primitive tests shared by both traversals ------------------------------------------------ */
 /* x?_rect::hit (geometry/aarect.h:79-135): t and the in-plane coordinates (a, b) */
+template <bool WAVE_EXIT = false>
 RT_DEV bool rect_hit_axes(const rtr_node& n, Real ok, Real dk, Real oa, Real da, Real ob, Real db, Real tmin, Real tmax,
                           Real& t, Real& a, Real& b) {
     /* same tests as aarect.h:80-88 (a NaN fails none of the rejects there, nor here), evaluated
-     * without early exits: lanes of a wave diverge on them anyway */
+     * without per-lane early exits: lanes of a wave diverge on them anyway */
     t = (n.f[4] - ok) / dk;
+    const bool off = (t < tmin) | (t > tmax);
+    /* WAVE_EXIT (shadow rays): the one exit that costs no divergence -- no lane of the wave reaches the plane
+     * inside its interval, e.g. every shadow ray against the walls of the room it starts in */
+    if (WAVE_EXIT && !__any(!off)) return false;
     a = oa + t * da;
     b = ob + t * db;
-    const bool out = (t < tmin) | (t > tmax) | (a < n.f[0]) | (a > n.f[1]) | (b < n.f[2]) | (b > n.f[3]);
+    const bool out = off | (a < n.f[0]) | (a > n.f[1]) | (b < n.f[2]) | (b > n.f[3]);
     return !out;
 }
+template <bool WAVE_EXIT = false>
 RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real tmax, Real& t, Real& a, Real& b) {
     /* one copy of the test per orientation: `type` is wave-uniform wherever the record came through
      * scalar loads, so this is a scalar branch, and no copy shuffles ray components through moves */
@@ -340,13 +346,13 @@ RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real 
      * body behind a chain of selects) */
     bool hit;
     if (type == RTR_NODE_XY_RECT) {
-        hit = rect_hit_axes(n, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t, a, b);
+        hit = rect_hit_axes<WAVE_EXIT>(n, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t, a, b);
         asm volatile("; xy_rect" : "+v"(t));
     } else if (type == RTR_NODE_XZ_RECT) {
-        hit = rect_hit_axes(n, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t, a, b);
+        hit = rect_hit_axes<WAVE_EXIT>(n, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t, a, b);
         asm volatile("; xz_rect" : "+v"(t));
     } else {
-        hit = rect_hit_axes(n, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t, a, b);
+        hit = rect_hit_axes<WAVE_EXIT>(n, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t, a, b);
         asm volatile("; yz_rect" : "+v"(t));
     }
     return hit;
@@ -655,11 +661,12 @@ RT_DEV bool boxray_hit(const BoxRay& r, const float* bmin, const float* bmax, fl
  * coplanar side faces of adjacent boxes in scene 9, are won by whichever primitive is tested
  * last; in the reference that is decided by 1-ulp noise of its BVH box tests, so neither order
  * can be called "the" reference behaviour.  Such faces share material and normal there.) */
+template <bool WAVE_EXIT = false>
 RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
     const int type = n.type;
     if (type >= RTR_NODE_XY_RECT) {
         Real a, b;
-        return rect_hit_t(n, type, o, d, tmin, tmax, t, a, b);
+        return rect_hit_t<WAVE_EXIT>(n, type, o, d, tmin, tmax, t, a, b);
     }
     V3 center;
     Real radius;
@@ -675,10 +682,10 @@ RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, Real time, Real tmin, R
  * 1-ulp noise of an UNPADDED box test (faces of `box` objects that touch: the later one is only
  * visited if aabb::hit of its box, entered at exactly that t, survives `t_max <= t_min`). */
 #define RT_TIE_FLAG (1 << 30)
-template <bool TIES = true>
+template <bool TIES = true, bool WAVE_EXIT = false>
 RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t, int& order) {
     const rtr_node n = ld_const(sc.fprim, ref);
-    if (!fast_prim_hit(n, o, d, time, tmin, tmax, t)) return false;
+    if (!fast_prim_hit<WAVE_EXIT>(n, o, d, time, tmin, tmax, t)) return false;
     const int tag = n.reserved;
     if (TIES && (tag & RT_TIE_FLAG)) {
         const int visit = tag & ~RT_TIE_FLAG;
@@ -723,7 +730,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
             const int r0 = I.ref_first, r1 = r0 + I.n_ref;
             for (int r = r0; r < r1; ++r) {
                 Real t;
-                if (fast_ref_hit<TREES>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
+                if (fast_ref_hit<TREES, ANY>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
                     tmax = t;
                     hit_ref = r;
                     hit_inst = ii;
@@ -762,7 +769,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                 const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
                 for (int r = r0; r < r1; ++r) {
                     Real t;
-                    if (fast_ref_hit<TREES>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
+                    if (fast_ref_hit<TREES, ANY>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
                         tmax = t;
                         tmax_f = float_above(t);
                         hit_ref = r;
