@@ -343,6 +343,10 @@ struct Validator {
 int params_check(rtr_context* c, const rtr_render_params* p) {
     if (!p) return fail(c, RTR_ERR_INVALID, "null params");
     if (p->image_width < 2 || p->image_height < 2) return fail(c, RTR_ERR_INVALID, "image smaller than 2x2");
+    /* tile indices are int32 and the tile list is materialised: 2^26 tiles = 131 072 x 131 072 pixels, more
+     * than a framebuffer in 288 GB of HBM holds */
+    if (((int64_t)p->image_width + 15) / 16 * (((int64_t)p->image_height + 15) / 16) > ((int64_t)1 << 26))
+        return fail(c, RTR_ERR_INVALID, "image larger than 2^26 tiles");
     if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->image_width || p->y1 > p->image_height || p->x0 >= p->x1 ||
         p->y0 >= p->y1)
         return fail(c, RTR_ERR_INVALID, "region outside the image or empty");

@@ -811,6 +811,14 @@ def test_error_behaviour(ctx, rtr):
     with pytest.raises(rtr.RtrError) as e:
         ctx.render(A.make_params(64, 64, 1, region=(0, 0, 65, 64)))
     assert e.value.code == A.RTR_ERR_INVALID
+    for w, h in [(2 ** 31 - 1, 2 ** 31 - 1), (2 ** 20, 2 ** 20), (1, 64), (64, 0)]:  # tile count would overflow / empty image
+        with pytest.raises(rtr.RtrError) as e:
+            ctx.plan_chunks(A.make_params(w, h, 1))
+        assert e.value.code == A.RTR_ERR_INVALID, (w, h)
+    for kw in [dict(spp_chunks=2), dict(tile_first=3, tile_stride=2), dict(flags=64), dict(pipeline=7), dict(max_depth=0)]:
+        with pytest.raises(rtr.RtrError) as e:
+            ctx.plan_chunks(A.make_params(64, 64, 1, **kw))
+        assert e.value.code == A.RTR_ERR_INVALID, kw
     bad = rtr.Scene.from_bytes(sc.to_bytes())
     bad.nodes["a"][bad.root] = 10 ** 6
     with pytest.raises(rtr.RtrError) as e:
