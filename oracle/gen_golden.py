@@ -182,7 +182,33 @@ def png_fixtures(manifest, note):
         note(name, cmd, info, source=src, width=w, height=h)
 
 
+TIE_SCENES = [1012, 1013]  # exact ties in t (harness scenes; a hittable_list and the same objects under a bvh_node)
+
+
+def tie_fixtures(note):
+    for sid in TIE_SCENES:
+        name = "scene%d.rtrs" % sid
+        cmd, info = run("dump-scene", sid, SCENE_SEED, os.path.join(GOLD, name))
+        note(name, cmd, info, raw_sha256=sha(os.path.join(GOLD, name)))
+        name = "hits_scene%d.bin" % sid
+        cmd, info = run("hits", sid, SCENE_SEED, 2048, 900 + sid, os.path.join(GOLD, name))
+        note(name, cmd, info, scene=sid)
+
+
 def main():
+    if "--add-ties" in sys.argv:  # only the tie fixtures, into the existing manifest
+        subprocess.run(["make", "-C", HERE, "_ref/ref_harness"], check=True)
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+
+        def note(name, cmd, info, **extra):
+            p = os.path.join(GOLD, name)
+            manifest["files"][name] = {"argv": [os.path.basename(cmd[0])] + cmd[1:-1] + [name], "info": info,
+                                       "sha256": sha(p), "bytes": os.path.getsize(p), **extra}
+        tie_fixtures(note)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return 0
     if "--add-png" in sys.argv:  # only the N3 fixtures, into the existing manifest
         subprocess.run(["make", "-C", HERE, "_ref/ref_harness"], check=True)
         with open(os.path.join(GOLD, "manifest.json")) as f:
@@ -379,6 +405,7 @@ def main():
     note(name, cmd, info, scene=21, integrator=4, width=128, height=info["height"], spp=32, seed=7)
 
     png_fixtures(manifest, note)
+    tie_fixtures(note)
 
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -375,6 +375,26 @@ static SceneConfig primitive_scene(int id) {
         c.world = make_shared<bvh_node>(w, 0, 1);
         break;
     }
+    case 1012:   /* exact ties in t: coplanar overlapping rects, a box face in the plane of a rect, the same sphere */
+    case 1013: { /* twice -- materials differ, so the hit record tells which one the reference's walk kept */
+        hittable_list w;
+        auto m = [](double r, double g, double b) { return make_shared<lambertian>(color(r, g, b)); };
+        w.add(make_shared<xz_rect>(-1.0, 0.8, -0.7, 1.1, 0.1, m(0.9, 0.1, 0.1)));
+        w.add(make_shared<xz_rect>(-0.5, 1.2, -0.2, 1.5, 0.1, m(0.1, 0.9, 0.1)));
+        w.add(make_shared<xy_rect>(-1.2, 0.3, -0.9, 0.6, 0.2, m(0.1, 0.1, 0.9)));
+        w.add(make_shared<xy_rect>(-0.4, 0.9, -0.1, 1.0, 0.2, m(0.9, 0.9, 0.1)));
+        w.add(make_shared<yz_rect>(-0.8, 0.5, -1.0, 0.4, -0.3, m(0.1, 0.9, 0.9)));
+        w.add(make_shared<yz_rect>(-0.2, 0.9, -0.5, 0.9, -0.3, m(0.9, 0.1, 0.9)));
+        w.add(make_shared<box>(point3(-0.6, -0.5, -0.4), point3(0.5, 0.1, 0.7), m(0.5, 0.5, 0.5))); /* top face in y = 0.1 */
+        w.add(make_shared<sphere>(point3(0.9, 0.7, -0.6), 0.35, m(0.8, 0.4, 0.2)));
+        w.add(make_shared<sphere>(point3(0.9, 0.7, -0.6), 0.35, m(0.2, 0.4, 0.8)));
+        w.add(make_shared<xz_rect>(-0.3, 0.6, 0.0, 0.9, 0.1, m(0.3, 0.3, 0.3))); /* a third one in y = 0.1, visited last */
+        if (id == 1012)
+            c.world = make_shared<hittable_list>(w);
+        else
+            c.world = make_shared<bvh_node>(w, 0, 1); /* split axes drawn from the scene seed (bvh.h:61-63) */
+        break;
+    }
     default: die("unknown primitive scene id");
     }
     c.aspect_ratio = 1.0;

@@ -38,7 +38,9 @@ namespace rtc {
 constexpr int kLinearMax = 12; /* instances with more references get a box tree */
 constexpr int kLeafMax = 4;
 constexpr int kGroupMax = 8; /* = the most references a leaf link can name (FBvh) */
-constexpr int kMaxInstances = 64;
+constexpr int kMaxInstances = 4096; /* instances of a sub-scene are scanned one after the other (each behind its world
+                                       box): a cost guard, not a correctness limit -- a flat hittable_list of hundreds of
+                                       transformed objects has no cheaper order in the reference either */
 constexpr int kMaxTreeDepth = 56; /* bounds the per-lane LDS stack of the box-tree traversal */
 
 struct Box {

@@ -656,7 +656,9 @@ inline int wf_alloc(WavefrontPool& pool, WfState& S, int n_slots, std::string& e
 
 template <typename K>
 inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
-    if (bytes > 160 * 1024)
+    hipFuncAttributes fa{};
+    WF_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)));
+    if (bytes + fa.sharedSizeBytes > 160 * 1024) /* static LDS of the kernel counts against the same 160 KiB */
         return wf_fail(err, RTR_ERR_UNSUPPORTED, "this traversal of the scene needs a deeper stack than 160 KiB of LDS holds");
     if (bytes > 64 * 1024)
         WF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -788,6 +788,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     if (int prc = params_check(c, p)) return prc;
     if (!d_rgb || row_stride < (int64_t)(p->x1 - p->x0)) return fail(c, RTR_ERR_INVALID, "bad output buffer / stride");
     HIPCHK(c, hipSetDevice(c->device));
+    (void)hipGetLastError(); /* a launch error of an earlier call (ours or the host framework's) is not this call's */
     int rc = RTR_OK;
 
     RenderK P{};

@@ -20,10 +20,12 @@ template <typename K>
 int launch_one(K kernel, const MegaLaunch& L, std::string& err) {
     /* the per-lane traversal stack lives in LDS: a graph that needs more than the CU has (e.g. the
      * reference-order walk of a hittable_list with thousands of direct children) cannot run that way */
-    if (L.lds > 160 * 1024)
+    hipFuncAttributes fa{};
+    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel));
+    /* the kernel's own static LDS (a few words of the workgroup vote) counts against the same 160 KiB */
+    if (e == hipSuccess && L.lds + fa.sharedSizeBytes > 160 * 1024)
         return mega_fail(err, RTR_ERR_UNSUPPORTED, "this traversal of the scene needs a deeper stack than 160 KiB of LDS holds");
-    hipError_t e = hipSuccess;
-    if (L.lds > 64 * 1024)
+    if (e == hipSuccess && L.lds > 64 * 1024)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
     if (e == hipSuccess && L.dry && L.blocks_per_cu)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(L.blocks_per_cu, kernel, RTR_BLOCK, L.lds);

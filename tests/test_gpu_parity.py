@@ -487,6 +487,32 @@ def test_primitive_hit_vectors(ctx, sid):
                 assert np.array_equal(_bits(out[f][uv]), _bits(gold[f][uv])), f
 
 
+@pytest.mark.parametrize("sid", [1012, 1013])
+def test_exact_ties_in_t_resolve_like_the_reference(ctx, sid):
+    """Coplanar overlapping rects, a box face in a rect's plane, the same sphere twice (harness scenes 1012: a
+    hittable_list, 1013: the same objects under a bvh_node): the material of the reference's hit record says which
+    object its walk kept.  The compiled traversal (tie-capable references carry their visiting position) and the
+    reference-order walk must keep the same one; a small render per pipeline on top."""
+    sc = _upload(ctx, sid)
+    gold = G.records("hits_scene%d.bin" % sid, A.HIT_DTYPE)
+    h = gold["hit"] == 1
+    assert G.rtr.native.validate_scene(sc)["fast_ok"]
+    for ref_order in (False, True):
+        ctx.reference_order(ref_order)
+        out = ctx.test_records("hits", gold)
+        ctx.reference_order(False)
+        assert np.array_equal(out["hit"], gold["hit"]), ref_order
+        for f in ("front_face", "material"):
+            assert np.array_equal(out[f][h], gold[f][h]), (f, ref_order)
+        for f in ("t", "p", "n"):
+            assert np.array_equal(_bits(out[f][h]), _bits(gold[f][h])), (f, ref_order)
+    want, wst = G.oracle_render(sc, A.make_params(64, 64, 4, integrator=1, seed=5))
+    for pipe, flags in ((A.PIPELINE_MEGAKERNEL, 0), (A.PIPELINE_MEGAKERNEL, A.FLAG_REFERENCE_ORDER), (A.PIPELINE_WAVEFRONT, 0)):
+        got = ctx.render(A.make_params(64, 64, 4, integrator=1, seed=5, pipeline=pipe, flags=flags))
+        assert np.array_equal(_bits(got), _bits(want)), (pipe, flags)
+        assert ctx.stats()["closest_segments"] == wst["closest_segments"]
+
+
 EVERY_SCENE = sorted(set(ALL_OTHER_SCENES) | {1, 4, 7, 8, 9, 15, 17, 18, 19, 21, 22, 23, 24, 26, 35})
 
 

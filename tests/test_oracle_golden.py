@@ -204,6 +204,33 @@ def test_primitive_hit_vectors(sid):
         assert np.any(gold["rng_in"] != gold["rng_out"])
 
 
+@pytest.mark.parametrize("sid", [1012, 1013])
+def test_exact_ties_in_t_resolve_like_the_reference(sid):
+    """Harness scenes 1012 / 1013: coplanar overlapping rects with different materials, a box face in the plane of
+    a rect, the same sphere twice -- as a hittable_list and under a bvh_node.  Every hit() of the reference
+    accepts t == t_max, so the object its walk visits later wins; `material` in the reference's vectors tells which."""
+    sc = G.scene(sid)
+    gold = G.records("hits_scene%d.bin" % sid, A.HIT_DTYPE)
+    out = G.oracle_records(sc, "rto_hits", gold)
+    h = gold["hit"] == 1
+    assert np.array_equal(out["hit"], gold["hit"]) and h.sum() > 800
+    for f in ("front_face", "material"):
+        assert np.array_equal(out[f][h], gold[f][h]), f
+    for f in ("t", "p", "n"):
+        assert np.array_equal(_bits(out[f][h]), _bits(gold[f][h])), f
+    # the vectors do contain ties: visiting the list backwards changes the winner of some rays
+    if sid == 1012:
+        root = sc.nodes[sc.root]
+        lc = sc.list_children.copy()
+        lc[root["a"]:root["a"] + root["b"]] = lc[root["a"]:root["a"] + root["b"]][::-1]
+        rev = G.rtr.Scene(sc.root, sc.nodes, lc, sc.materials, sc.textures, sc.perlin, sc.images, sc.image_bytes,
+                          sc.lights, sc.camera, sc.background)
+        other = G.oracle_records(rev, "rto_hits", gold)
+        assert np.array_equal(other["hit"], gold["hit"])
+        assert 100 < int((other["material"][h] != gold["material"][h]).sum())
+        assert np.array_equal(_bits(other["t"][h]), _bits(gold["t"][h]))  # same t, another winner
+
+
 ALL_OTHER_SCENES = [2, 5, 6, 10, 11, 12, 13, 14, 16, 20, 25, 27, 28, 30, 31, 32, 33, 34, 36, 37, 38, 39, 40, 41, 42]
 
 

@@ -1,0 +1,110 @@
+"""Random scenes (tests/_randscene.py) through the C ABI against the pinned CPU oracle: hit records of every
+traversal and small renders of every integrator on both pipelines.  The golden scenes are the reference's
+forty demo scenes; these graphs add what none of them contains -- coplanar overlapping rects (exact ties in t),
+media in the middle of the visiting order next to transformed boxes, dozens of small instances, nested lists
+under transforms -- with the oracle (bit-exact against the reference on every golden vector) as the checker."""
+import numpy as np
+import pytest
+
+import _golden as G
+import _randscene as R
+
+A = G.A
+rtr = G.rtr
+
+CASES = [(11, {}), (12, {}), (13, dict(n_objects=90)), (14, dict(media=True)), (15, dict(media=True, n_objects=60)),
+         (16, dict(hollow=True)), (17, dict(n_objects=8, ties=True)), (18, dict(media=True, hollow=True)),
+         (19, dict(n_objects=200)), (20, dict(n_objects=40)), (21, dict(media=True, n_objects=12)),
+         (22, dict(n_objects=3)), (23, dict(media=True, n_objects=100)), (24, dict(n_objects=60)),
+         (25, dict(media=True)), (26, dict(n_objects=30, hollow=True))]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+@pytest.mark.parametrize("seed,kw", CASES)
+def test_random_scenes_validate_and_run_on_the_oracle(seed, kw):
+    """CPU: the generator's scenes are well-formed and the oracle traces them (no GPU)."""
+    sc = R.random_scene(seed, **kw)
+    info = rtr.native.validate_scene(sc)
+    assert info["has_media"] == bool(kw.get("media")) and info["inverted_boxes"] == (1 if kw.get("hollow") else 0)
+    if not kw.get("media") and not kw.get("hollow"):
+        assert info["fast_ok"] and info["fast_refs"] >= 3
+    if kw.get("media") and not kw.get("hollow"):
+        assert info["program_steps"] >= 4  # media under lists only: the step program exists
+    rays = R.random_rays(seed, 500)
+    out = G.oracle_records(sc, "rto_hits", rays)
+    assert 50 < int(out["hit"].sum()) <= 500
+    img, st = G.oracle_render(sc, A.make_params(24, 16, 2, integrator=4, seed=seed))
+    assert np.isfinite(img).all() and img.mean() > 0 and st["samples"] == 24 * 16 * 2
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rtr.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", CASES)
+def test_random_scene_hit_records_equal_the_oracle(ctx, seed, kw):
+    sc = R.random_scene(seed, **kw)
+    ctx.upload(sc)
+    rays = R.random_rays(seed, 6000)
+    ora = G.oracle_records(sc, "rto_hits", rays)
+    h = ora["hit"] == 1
+    # moving_sphere::hit writes no (u,v) (moving_sphere.h:36-62): nothing to compare there
+    moving = np.isin(ora["material"], sc.nodes["a"][sc.nodes["type"] == A.NODE_MOVING_SPHERE])
+    for exact_order in (False, True):
+        ctx.reference_order(exact_order)
+        dev = ctx.test_records("hits", rays)
+        ctx.reference_order(False)
+        tag = "random%02d.%s" % (seed, "reference_order" if exact_order else "compiled")
+        assert np.array_equal(dev["hit"], ora["hit"]), tag
+        for f in ("front_face", "material", "rng_out"):
+            assert np.array_equal(dev[f][h] if f != "rng_out" else dev[f], ora[f][h] if f != "rng_out" else ora[f]), (tag, f)
+        # a constant_medium's t is t1 + hit_distance / |d| with hit_distance = -1/density * log(random)
+        # (constant_medium.h:88-96): OCML's log against glibc's, last bits; surfaces are +-*/sqrt only
+        fog = h & np.isin(ora["material"], np.flatnonzero(sc.materials["type"] == A.MAT_ISOTROPIC))
+        surf = h & ~fog
+        for f in ("t", "p", "n"):
+            bad = int((_bits(dev[f][surf]) != _bits(ora[f][surf])).reshape(int(surf.sum()), -1).any(axis=1).sum())
+            assert bad == 0, (tag, f, bad)
+            assert np.allclose(dev[f][fog], ora[f][fog], rtol=1e-13, atol=1e-13), (tag, f, "medium")
+        uv = surf & ~moving
+        # sphere (u,v) go through acos / atan2 (OCML on the device, glibc in the oracle): last bits may differ
+        for f in ("u", "v"):
+            assert np.allclose(dev[f][uv], ora[f][uv], rtol=0, atol=1e-12), (tag, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", CASES)
+def test_random_scene_renders_equal_the_oracle(ctx, seed, kw):
+    sc = R.random_scene(seed, **kw)
+    ctx.upload(sc)
+    info = rtr.native.validate_scene(sc)
+    wavefront = info["fast_ok"] or info["program_steps"] > 0
+    worst = 0.0
+    for integ in (0, 1, 2, 3, 4):
+        p = A.make_params(48, 32, 4, integrator=integ, seed=100 + seed)
+        want, wst = G.oracle_render(sc, p)
+        runs = [(A.PIPELINE_MEGAKERNEL, 0), (A.PIPELINE_MEGAKERNEL, A.FLAG_REFERENCE_ORDER)]
+        if wavefront:
+            runs.append((A.PIPELINE_WAVEFRONT, 0))
+        for pipe, flags in runs:
+            try:
+                got = ctx.render(A.make_params(48, 32, 4, integrator=integ, seed=100 + seed, pipeline=pipe, flags=flags))
+            except rtr.RtrError as e:
+                # the reference-order walk keeps one stack word per direct child of a hittable_list in LDS: a flat
+                # list of 120 objects plus the parked path state of the light-sampling integrators is over 160 KiB
+                assert flags == A.FLAG_REFERENCE_ORDER and e.code == A.RTR_ERR_UNSUPPORTED and info["stack_words"] > 100, (seed, integ, pipe, flags, e)
+                continue
+            st = ctx.stats()
+            tag = "random%02d.i%d.pipe%d.flags%d" % (seed, integ, pipe, flags)
+            assert st["closest_segments"] == wst["closest_segments"] and st["shadow_segments"] == wst["shadow_segments"], tag
+            err = G.rel_l2(got, want)
+            worst = max(worst, err)
+            assert err <= 1e-12, (tag, err)  # same paths (segment counts equal); libm last bits only
+    G.residue("random%02d.renders.worst_rel_l2" % seed, worst, 1e-12)
