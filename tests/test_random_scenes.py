@@ -59,8 +59,13 @@ def test_random_scene_hit_records_equal_the_oracle(ctx, seed, kw):
     moving = np.isin(ora["material"], sc.nodes["a"][sc.nodes["type"] == A.NODE_MOVING_SPHERE])
     for exact_order in (False, True):
         ctx.reference_order(exact_order)
-        dev = ctx.test_records("hits", rays)
-        ctx.reference_order(False)
+        try:
+            dev = ctx.test_records("hits", rays)
+        except rtr.RtrError as e:  # one LDS stack word per direct child of a flat list: 160 KiB end at ~150 of them
+            assert exact_order and e.code == A.RTR_ERR_UNSUPPORTED and rtr.native.validate_scene(sc)["stack_words"] > 150, e
+            continue
+        finally:
+            ctx.reference_order(False)
         tag = "random%02d.%s" % (seed, "reference_order" if exact_order else "compiled")
         assert np.array_equal(dev["hit"], ora["hit"]), tag
         for f in ("front_face", "material", "rng_out"):
