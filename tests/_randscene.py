@@ -16,6 +16,7 @@ class Builder:
     def __init__(self, rng):
         self.rng = rng
         self.nodes, self.kids, self.mats, self.texs, self.lights = [], [], [], [], []
+        self.uses_noise = False
 
     # ---- records ---------------------------------------------------------------------------------
     def node(self, type_, a=0, b=0, f=()):
@@ -38,6 +39,14 @@ class Builder:
         self.texs.append(t)
         return len(self.texs) - 1
 
+    def noise(self, scale):
+        t = np.zeros(1, dtype=A.TEXTURE_DTYPE)
+        t["type"], t["a"] = A.TEX_NOISE, 0  # perlin table 0 (the scene carries scene 9's)
+        t["f"][0, 0] = scale
+        self.texs.append(t)
+        self.uses_noise = True
+        return len(self.texs) - 1
+
     def material(self, type_, tex=(), f=()):
         m = np.zeros(1, dtype=A.MATERIAL_DTYPE)
         m["type"] = type_
@@ -53,6 +62,8 @@ class Builder:
     def random_material(self, allow_glass=True):
         r = self.rng
         k = int(r.integers(0, 6 if allow_glass else 5))
+        if k == 0 and r.random() < 0.3:  # marble-like noise_texture (texture.h:78-92)
+            return self.material(A.MAT_LAMBERTIAN, [self.noise(float(r.uniform(0.5, 6.0)))])
         if k == 0:
             return self.material(A.MAT_LAMBERTIAN, [self.solid(r.uniform(0.1, 0.9, 3))])
         if k == 1:
@@ -111,11 +122,18 @@ class Builder:
         self.lights.append(l)
 
 
+    def simple_light(self, type_, f):
+        l = np.zeros(1, dtype=A.LIGHT_DTYPE)
+        l["type"] = type_
+        l["f"][0, :len(f)] = f
+        self.lights.append(l)
+
+
 def _cat(parts, dtype):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=dtype)
 
 
-def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True):
+def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta_lights=False):
     """One scene in front of scene 23's camera (origin (0,3,8), looking at the origin)."""
     rng = np.random.default_rng(seed)
     b = Builder(rng)
@@ -130,6 +148,14 @@ def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True):
     lx0, lx1, lz0, lz1, ly = -2.0, 2.0, -3.0, 0.0, 6.0
     top.append(b.flip_face(b.rect("xz", lx0, lx1, lz0, lz1, ly, emit)))
     b.quad_light([lx0, ly, lz0], [lx1 - lx0, 0.0, 0.0], [0.0, 0.0, lz1 - lz0], [7.0, 7.0, 7.0])
+
+    if delta_lights:  # lighting/point_light.h, spot_light.h, directional_light.h, environmental_light.h without a map
+        b.simple_light(A.LIGHT_POINT, [3.0, 4.5, 1.0, 9.0, 8.0, 6.0])
+        d = np.array([-0.3, -1.0, -0.2])
+        b.simple_light(A.LIGHT_SPOT, [-3.0, 5.0, 0.0] + list(d / np.linalg.norm(d)) + [20.0, 20.0, 25.0, np.cos(np.radians(35.0))])
+        d = np.array([0.4, -1.0, 0.3])
+        b.simple_light(A.LIGHT_DIRECTIONAL, list(d / np.linalg.norm(d)) + [0.6, 0.5, 0.4])
+        b.simple_light(A.LIGHT_ENV_UNIFORM, [])
 
     def pos(lo=(-4.5, 0.3, -6.0), hi=(4.5, 3.5, 2.0)):
         return rng.uniform(lo, hi)
@@ -181,7 +207,8 @@ def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True):
         top = [top[i] for i in order]
     root = b.hlist(top)
     sc = rtr.Scene(root, _cat(b.nodes, A.NODE_DTYPE), np.asarray(b.kids, dtype=np.int32), _cat(b.mats, A.MATERIAL_DTYPE),
-                   _cat(b.texs, A.TEXTURE_DTYPE), base.perlin[:0], base.images[:0], base.image_bytes[:0],
+                   _cat(b.texs, A.TEXTURE_DTYPE), G.scene(9).perlin[:1] if b.uses_noise else base.perlin[:0],
+                   base.images[:0], base.image_bytes[:0],
                    _cat(b.lights, A.LIGHT_DTYPE), base.camera.copy(), np.array([0.55, 0.65, 0.8]))
     return sc
 
