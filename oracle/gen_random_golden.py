@@ -71,6 +71,20 @@ def main():
                             str(100 + seed), name], json.loads(out.strip().splitlines()[-1]), scene="random_%02d" % seed,
                      integrator=integ, width=W, height=H, spp=SPP, seed=100 + seed)
             print("random_%02d done" % seed, flush=True)
+        # exact ties in t ACROSS transform chains (box faces in the planes of rects visited before and after them)
+        sc = R.cross_instance_tie_scene()
+        raw = os.path.join(td, "xties.rtrs")
+        sc.save(raw)
+        with open(raw, "rb") as f, open(os.path.join(GOLD, "xties.rtrs.gz"), "wb") as fo, \
+                gzip.GzipFile(filename="", fileobj=fo, mode="wb", mtime=0) as g:
+            g.write(f.read())
+        note("xties.rtrs.gz", ["tests/_randscene.py: cross_instance_tie_scene()"], {}, raw_sha256=sha(raw))
+        rays = os.path.join(td, "xrays.bin")
+        R.cross_instance_tie_rays().tofile(rays)
+        out = subprocess.run([HARNESS, "hits-rtrs", raw, rays, os.path.join(GOLD, "xties_hits.bin")], check=True,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        note("xties_hits.bin", ["ref_harness", "hits-rtrs", "xties.rtrs", "cross_instance_tie_rays()", "xties_hits.bin"],
+             json.loads(out.strip().splitlines()[-1]), scene="xties")
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     return 0

@@ -712,6 +712,70 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
                     }
             }
         }
+        /* Ties ACROSS instances of a sub-scene.  Instances are scanned in the order their first primitive is
+         * visited and every test accepts t == t_max, so of two instances the later one wins a tie -- which is the
+         * reference's choice (it keeps what it visits later) unless the EARLIER instance holds the later-visited
+         * primitive (all primitives under the same transform chain share an instance: [wall, box, floor] puts the
+         * floor into the first instance, in front of the box whose bottom face lies in its plane).  Exactly those
+         * pairs -- rects whose planes coincide in world space, visiting order against instance order -- get the
+         * tie flag; their visiting positions then decide.  A y-plane keeps its orientation under every chain
+         * (translate, rotate_y), x- and z-planes under translations only; rotated side faces of different
+         * chains are not looked at. */
+        for (const FSub& sub : cs.subs) {
+            struct PlaneRef {
+                double k;
+                int axis, inst, ref, visit;
+            };
+            std::vector<PlaneRef> planes;
+            for (int ii = sub.inst_first; ii < sub.inst_first + sub.n_inst; ++ii) {
+                const FInst& I = cs.inst[ii];
+                double off[3] = {0, 0, 0};
+                bool rotated = false;
+                for (int k = 0; k < I.n_xf; ++k) {
+                    const FXf& x = cs.xf[I.xf_first + k];
+                    if (x.type == RTR_NODE_TRANSLATE)
+                        off[0] += x.f[0], off[1] += x.f[1], off[2] += x.f[2];
+                    else
+                        rotated = true;
+                }
+                for (int r = I.ref_first; r < I.ref_first + I.n_ref; ++r) {
+                    const rtr_node& n = prims[r];
+                    if (n.type < RTR_NODE_XY_RECT) continue;
+                    const int axis = n.type == RTR_NODE_XY_RECT ? 2 : (n.type == RTR_NODE_XZ_RECT ? 1 : 0);
+                    if (rotated && axis != 1) continue;
+                    planes.push_back({n.f[4] + off[axis], axis, ii, r, n.reserved & ~RT_TIE_FLAG});
+                }
+            }
+            std::sort(planes.begin(), planes.end(), [](const PlaneRef& a, const PlaneRef& b) {
+                return a.axis != b.axis ? a.axis < b.axis : a.k < b.k;
+            });
+            for (size_t lo = 0; lo < planes.size();) { /* clusters of (nearly) the same world plane */
+                size_t hi = lo + 1;
+                while (hi < planes.size() && planes[hi].axis == planes[lo].axis &&
+                       planes[hi].k - planes[hi - 1].k <= 1e-9 * std::max(1.0, std::fabs(planes[hi].k)))
+                    ++hi;
+                if (hi - lo > 1) {
+                    std::vector<PlaneRef> cl(planes.begin() + lo, planes.begin() + hi);
+                    std::sort(cl.begin(), cl.end(), [](const PlaneRef& a, const PlaneRef& b) { return a.inst < b.inst; });
+                    /* flag P (earlier instance) and Q (later instance) whenever visit(P) > visit(Q) */
+                    std::vector<int> max_before(cl.size()), min_after(cl.size());
+                    int mx = -1;
+                    for (size_t i = 0, j = 0; i < cl.size(); i = j) { /* per instance block */
+                        for (j = i; j < cl.size() && cl[j].inst == cl[i].inst; ++j) max_before[j] = mx;
+                        for (size_t q = i; q < j; ++q) mx = std::max(mx, cl[q].visit);
+                    }
+                    int mn = INT32_MAX;
+                    for (size_t j = cl.size(), i; j > 0; j = i) {
+                        for (i = j; i > 0 && cl[i - 1].inst == cl[j - 1].inst; --i) min_after[i - 1] = mn;
+                        for (size_t q = i; q < j; ++q) mn = std::min(mn, cl[q].visit);
+                    }
+                    for (size_t q = 0; q < cl.size(); ++q)
+                        if (max_before[q] > cl[q].visit || min_after[q] < cl[q].visit)
+                            prims[cl[q].ref].reserved |= RT_TIE_FLAG, any_tie = true;
+                }
+                lo = hi;
+            }
+        }
         if ((rc = upload(c, c->b_fprim, prims.data(), sizeof(rtr_node) * prims.size()))) return rc;
     }
     c->fast_stack_words = cs.stack_words;

@@ -223,3 +223,39 @@ def random_rays(seed, n):
     rays["t_min"], rays["t_max"] = 0.001, np.inf
     rays["rng_in"] = rng.integers(1, 2 ** 32 - 1, n, dtype=np.uint64).astype(np.uint32)
     return rays
+
+
+def cross_instance_tie_scene():
+    """Exact ties in t between objects under DIFFERENT transform chains: faces of translated (and rotated) boxes in
+    the planes of rects that the list visits before and after them.  The reference keeps whatever it visits later."""
+    b = Builder(np.random.default_rng(0))
+    m = [b.material(A.MAT_LAMBERTIAN, [b.solid(c)]) for c in ([.9, .1, .1], [.1, .9, .1], [.1, .1, .9], [.9, .9, .1],
+                                                             [.1, .9, .9], [.9, .1, .9], [.5, .5, .5])]
+    floor_a = b.rect("xz", -5, 5, -5, 5, 0.0, m[0])
+    back = b.rect("xy", -5, 5, -1, 4, 1.5, m[5])
+    t1 = b.translate(b.rotate_y(b.box([0, 0, 0], [1, 1.5, 1], m[1]), 20.0), [0.5, 0.0, -1.0])  # bottom in y = 0
+    floor_b = b.rect("xz", -1, 3, -3, 1, 0.0, m[2])  # same transform chain as floor_a, visited AFTER t1
+    t2 = b.translate(b.box([0, 0, 0], [1, 1, 1], m[3]), [-2.0, 0.0, 0.5])  # faces in x = -2, z = 1.5, y = 0
+    side = b.rect("yz", -1, 4, -5, 5, -2.0, m[4])  # visited after t2
+    t3 = b.translate(b.translate(b.box([0, 0, 0], [0.5, 0.5, 0.5], m[6]), [1.0, 0.0, 0.0]), [1.5, 0.0, 1.0])  # z = 1.5 again
+    root = b.hlist([floor_a, back, t1, floor_b, t2, side, t3])
+    base = G.scene(23)
+    return rtr.Scene(root, _cat(b.nodes, A.NODE_DTYPE), np.asarray(b.kids, dtype=np.int32), _cat(b.mats, A.MATERIAL_DTYPE),
+                     _cat(b.texs, A.TEXTURE_DTYPE), base.perlin[:0], base.images[:0], base.image_bytes[:0], base.lights[:0],
+                     base.camera.copy(), np.array([0.5, 0.6, 0.8]))
+
+
+def cross_instance_tie_rays(n=1536):
+    rng = np.random.default_rng(5)
+    r = np.zeros(n, dtype=A.HIT_DTYPE)
+    k = n // 3
+    o, t = np.empty((n, 3)), np.empty((n, 3))
+    o[:k] = rng.uniform((-3, -3, -3), (3.5, -0.5, 3), (k, 3))  # from below the floors, up into the boxes
+    t[:k] = rng.uniform((-2.2, 0.2, -1.2), (3.2, 1.2, 1.8), (k, 3))
+    o[k:2 * k] = rng.uniform((-6, 0.1, -1), (-2.5, 2, 3), (k, 3))  # from x < -2 into the translated box
+    t[k:2 * k] = rng.uniform((-1.9, 0.1, 0.6), (-1.1, 0.9, 1.4), (k, 3))
+    o[2 * k:] = rng.uniform((-3, 0.1, 2), (4, 2, 5), (n - 2 * k, 3))  # from z > 1.5
+    t[2 * k:] = rng.uniform((-1.9, 0.05, 0.6), (3.0, 0.9, 1.45), (n - 2 * k, 3))
+    r["o"], r["d"] = o, t - o
+    r["time"], r["t_min"], r["t_max"], r["rng_in"] = 0.5, 0.001, np.inf, 7
+    return r

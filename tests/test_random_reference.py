@@ -61,6 +61,25 @@ def test_oracle_equals_the_reference_on_random_scenes(seed):
         assert st["closest_segments"] + st["shadow_segments"] == info["closest_segments"] + info["shadow_segments"]
 
 
+def _xties():
+    with gzip.open(os.path.join(G.GOLD, "xties.rtrs.gz"), "rb") as f:
+        sc = rtr.Scene.from_bytes(f.read())
+    return sc, G.records("xties_hits.bin", A.HIT_DTYPE)
+
+
+def test_oracle_resolves_ties_across_transform_chains_like_the_reference():
+    """Faces of translated / rotated boxes in the planes of rects the list visits before AND after them: the
+    material of the reference's record says which object its walk kept (the later one)."""
+    sc, gold = _xties()
+    out = G.oracle_records(sc, "rto_hits", gold)
+    h = gold["hit"] == 1
+    assert h.all() and np.array_equal(out["hit"], gold["hit"])
+    assert np.array_equal(out["material"], gold["material"]) and np.array_equal(out["front_face"], gold["front_face"])
+    for f in ("t", "p", "n"):
+        assert np.array_equal(_bits(out[f]), _bits(gold[f])), f
+    assert len(np.unique(gold["material"])) >= 5  # walls before, walls after and boxes all win somewhere
+
+
 @pytest.fixture(scope="module")
 def ctx():
     c = rtr.Context(0)
@@ -106,3 +125,27 @@ def test_device_equals_the_reference_on_random_scenes(ctx, seed):
             worst = max(worst, err)
             assert err <= 1e-12, (seed, integ, pipe, err)
     G.residue("random%02d.vs_reference.worst_rel_l2" % seed, worst, 1e-12)
+
+
+@pytest.mark.gpu
+def test_device_resolves_ties_across_transform_chains_like_the_reference(ctx):
+    """The compiled traversal scans instances (one per transform chain) in the order their FIRST primitive is visited;
+    where that contradicts the visiting order of two coplanar faces (floor_b sits in the first instance but is
+    visited after the box whose bottom lies in its plane) upload flags the pair and their visiting positions decide."""
+    sc, gold = _xties()
+    ctx.upload(sc)
+    assert rtr.native.validate_scene(sc)["fast_ok"]
+    for ref_order in (False, True):
+        ctx.reference_order(ref_order)
+        out = ctx.test_records("hits", gold)
+        ctx.reference_order(False)
+        assert np.array_equal(out["hit"], gold["hit"]), ref_order
+        wrong = int((out["material"] != gold["material"]).sum())
+        assert wrong == 0, (ref_order, wrong)
+        assert np.array_equal(out["front_face"], gold["front_face"]), ref_order
+        for f in ("t", "p", "n"):
+            assert np.array_equal(_bits(out[f]), _bits(gold[f])), (f, ref_order)
+    want, _ = G.oracle_render(sc, A.make_params(W, H, SPP, integrator=1, seed=9))
+    for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
+        got = ctx.render(A.make_params(W, H, SPP, integrator=1, seed=9, pipeline=pipe))
+        assert np.array_equal(_bits(got), _bits(want)), pipe
