@@ -678,7 +678,11 @@ RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, Real time, Real tmin, R
  * the references that can tie with another one of their instance (same plane and overlapping extent,
  * or the same sphere twice) with RT_TIE_FLAG and stores their visiting position next to it; only those
  * pay for the comparison: a tie is accepted only from a primitive visited later than the current
- * holder.  Not reproduced: ties across instances, and ties where the reference's own choice hangs on
+ * holder.  Across instances the scan order is the visiting order of each instance's first primitive and
+ * `t == t_max` is accepted, so the later instance wins like the reference's later visit; coplanar rects
+ * whose instance order contradicts their visiting order are flagged as well (rtr_upload_scene), their
+ * positions are comparable because `order` lives across the instance loop.  Not reproduced: coplanar
+ * rotated faces of two different transform chains, and ties where the reference's own choice hangs on
  * 1-ulp noise of an UNPADDED box test (faces of `box` objects that touch: the later one is only
  * visited if aabb::hit of its box, entered at exactly that t, survives `t_max <= t_min`). */
 #define RT_TIE_FLAG (1 << 30)
