@@ -29,6 +29,11 @@ CASES = [(11, {}), (13, dict(n_objects=90)), (14, dict(media=True)), (15, dict(m
          (16, dict(hollow=True)), (17, dict(n_objects=8, ties=True)), (18, dict(media=True, hollow=True)),
          (19, dict(n_objects=200)), (27, dict(delta_lights=True)), (28, dict(delta_lights=True, media=True))]
 W, H, SPP, N_RAYS = 48, 32, 4, 512
+# the same generator output under the reference's own bvh_node (harness command wrap-bvh: its constructor draws the
+# split axes): fixtures random_<seed>b.*
+BVH_CASES = [(13, dict(n_objects=90)), (15, dict(media=True, n_objects=60)), (16, dict(hollow=True)),
+             (18, dict(media=True, hollow=True)), (19, dict(n_objects=200)), (23, dict(media=True, n_objects=100)),
+             (26, dict(n_objects=30, hollow=True)), (28, dict(delta_lights=True, media=True))]
 
 
 def sha(path):
@@ -46,31 +51,38 @@ def main():
         manifest["files"][name] = {"argv": argv, "info": info, "sha256": sha(p), "bytes": os.path.getsize(p), **extra}
 
     with tempfile.TemporaryDirectory() as td:
-        for seed, kw in CASES:
+        for seed, kw, wrap in [(s_, k_, False) for s_, k_ in CASES] + [(s_, k_, True) for s_, k_ in BVH_CASES]:
             sc = R.random_scene(seed, **kw)
             raw = os.path.join(td, "scene.rtrs")
             sc.save(raw)
-            name = "random_%02d.rtrs.gz" % seed
+            tag = "%02d" % seed
+            if wrap:
+                flat, raw, tag = raw, os.path.join(td, "scene_bvh.rtrs"), "%02db" % seed
+                subprocess.run([HARNESS, "wrap-bvh", flat, str(777 + seed), raw], check=True, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL)
+            name = "random_%s.rtrs.gz" % tag
             with open(raw, "rb") as f, open(os.path.join(GOLD, name), "wb") as fo, \
                     gzip.GzipFile(filename="", fileobj=fo, mode="wb", mtime=0) as g:
                 g.write(f.read())
-            note(name, ["tests/_randscene.py: random_scene(%d, **%r)" % (seed, kw)], {}, raw_sha256=sha(raw))
+            note(name, ["tests/_randscene.py: random_scene(%d, **%r)" % (seed, kw)] +
+                 (["ref_harness", "wrap-bvh", "<that scene>", str(777 + seed), "random_%s.rtrs" % tag] if wrap else []), {},
+                 raw_sha256=sha(raw))
             rays = os.path.join(td, "rays.bin")
             R.random_rays(seed, N_RAYS).tofile(rays)
-            name = "random_%02d_hits.bin" % seed
+            name = "random_%s_hits.bin" % tag
             out = subprocess.run([HARNESS, "hits-rtrs", raw, rays, os.path.join(GOLD, name)], check=True,
                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
-            note(name, ["ref_harness", "hits-rtrs", "random_%02d.rtrs" % seed, "random_rays(%d, %d)" % (seed, N_RAYS), name],
-                 json.loads(out.strip().splitlines()[-1]), scene="random_%02d" % seed)
+            note(name, ["ref_harness", "hits-rtrs", "random_%s.rtrs" % tag, "random_rays(%d, %d)" % (seed, N_RAYS), name],
+                 json.loads(out.strip().splitlines()[-1]), scene="random_%s" % tag)
             for integ in (1, 4):
-                name = "random_%02d_i%d.f64" % (seed, integ)
+                name = "random_%s_i%d.f64" % (tag, integ)
                 out = subprocess.run([HARNESS, "render-rtrs", raw, str(integ), str(W), str(H), str(SPP), str(100 + seed),
                                       os.path.join(GOLD, name)], check=True, stdout=subprocess.PIPE,
                                      stderr=subprocess.DEVNULL).stdout.decode()
-                note(name, ["ref_harness", "render-rtrs", "random_%02d.rtrs" % seed, str(integ), str(W), str(H), str(SPP),
-                            str(100 + seed), name], json.loads(out.strip().splitlines()[-1]), scene="random_%02d" % seed,
+                note(name, ["ref_harness", "render-rtrs", "random_%s.rtrs" % tag, str(integ), str(W), str(H), str(SPP),
+                            str(100 + seed), name], json.loads(out.strip().splitlines()[-1]), scene="random_%s" % tag,
                      integrator=integ, width=W, height=H, spp=SPP, seed=100 + seed)
-            print("random_%02d done" % seed, flush=True)
+            print("random_%s done" % tag, flush=True)
         # exact ties in t ACROSS transform chains (box faces in the planes of rects visited before and after them)
         sc = R.cross_instance_tie_scene()
         raw = os.path.join(td, "xties.rtrs")

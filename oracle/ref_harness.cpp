@@ -543,6 +543,25 @@ struct Unflattener {
         case RTR_NODE_ROTATE_Y: {
             auto ro = make_shared<rotate_y>(node(n.a), 0.0);
             ro->sin_theta = n.f[0], ro->cos_theta = n.f[1];
+            /* the box the constructor would have derived from this sin / cos (hittable.h:100-124, restated: the
+             * constructor ran with angle 0) -- a bvh_node built over the object reads it */
+            ro->hasbox = ro->ptr->bounding_box(0, 1, ro->bbox);
+            point3 mn(infinity, infinity, infinity), mx(-infinity, -infinity, -infinity);
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++)
+                    for (int k = 0; k < 2; k++) {
+                        auto x = i * ro->bbox.max().x() + (1 - i) * ro->bbox.min().x();
+                        auto y = j * ro->bbox.max().y() + (1 - j) * ro->bbox.min().y();
+                        auto z = k * ro->bbox.max().z() + (1 - k) * ro->bbox.min().z();
+                        auto newx = ro->cos_theta * x + ro->sin_theta * z;
+                        auto newz = -ro->sin_theta * x + ro->cos_theta * z;
+                        vec3 tester(newx, y, newz);
+                        for (int c = 0; c < 3; c++) {
+                            mn[c] = fmin(mn[c], tester[c]);
+                            mx[c] = fmax(mx[c], tester[c]);
+                        }
+                    }
+            ro->bbox = aabb(mn, mx);
             r = ro;
             break;
         }
@@ -655,6 +674,21 @@ static int cmd_dump_scene(int scene_id, uint32_t scene_seed, const char* path) {
                 "\"default_width\": %d, \"default_height\": %d, \"default_spp\": %d}\n",
                 scene_id, f.out.nodes.size(), f.out.materials.size(), f.out.textures.size(), f.out.lights.size(),
                 l.default_w, l.default_h, l.cfg.samples_per_pixel);
+    return 0;
+}
+
+/* Wrap the children of a scene FILE's root hittable_list into the reference's own bvh_node (its constructor draws
+ * the split axes from the RNG, bvh.h:53-99) and write the graph back: random scenes under the acceleration
+ * structure the reference's scene builders put around their worlds. */
+static int cmd_wrap_bvh(const char* in_path, uint32_t seed, const char* out_path) {
+    LoadedFile lf = load_rtrs(in_path);
+    auto list = std::dynamic_pointer_cast<hittable_list>(lf.l.cfg.world);
+    if (!list) die("wrap-bvh: the root of the scene file is not a hittable_list");
+    set_rng(seed);
+    lf.l.cfg.world = make_shared<bvh_node>(*list, 0, 1);
+    Flattener f = flatten(lf.l);
+    if (!f.out.save(out_path)) die("cannot write scene file");
+    std::printf("{\"nodes\": %zu, \"materials\": %zu}\n", f.out.nodes.size(), f.out.materials.size());
     return 0;
 }
 
@@ -1117,6 +1151,7 @@ int main(int argc, char** argv) {
         return cmd_materials(I(2), U(3), I(4), std::strtoull(argv[5], nullptr, 0), argv[6]);
     if (c == "lights" && argc == 7) return cmd_lights(I(2), U(3), I(4), std::strtoull(argv[5], nullptr, 0), argv[6]);
     if (c == "rng" && argc == 3) return cmd_rng(argv[2]);
+    if (c == "wrap-bvh" && argc == 5) return cmd_wrap_bvh(argv[2], U(3), argv[4]);
     if (c == "hits-rtrs" && argc == 5) return cmd_hits_rtrs(argv[2], argv[3], argv[4]);
     if (c == "render-rtrs" && argc == 9) return cmd_render_rtrs(argv[2], I(3), I(4), I(5), I(6), U(7), argv[8]);
 #endif
