@@ -133,7 +133,7 @@ def _cat(parts, dtype):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=dtype)
 
 
-def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta_lights=False):
+def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta_lights=False, lens=0.0):
     """One scene in front of scene 23's camera (origin (0,3,8), looking at the origin)."""
     rng = np.random.default_rng(seed)
     b = Builder(rng)
@@ -206,10 +206,12 @@ def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta
         order = rng.permutation(len(top))  # media anywhere in the visiting order, not only at its end
         top = [top[i] for i in order]
     root = b.hlist(top)
+    camera = base.camera.copy()
+    camera["lens_radius"] = lens  # camera.h:33-39: the defocus disk is drawn for every ray, used when the lens is open
     sc = rtr.Scene(root, _cat(b.nodes, A.NODE_DTYPE), np.asarray(b.kids, dtype=np.int32), _cat(b.mats, A.MATERIAL_DTYPE),
                    _cat(b.texs, A.TEXTURE_DTYPE), G.scene(9).perlin[:1] if b.uses_noise else base.perlin[:0],
                    base.images[:0], base.image_bytes[:0],
-                   _cat(b.lights, A.LIGHT_DTYPE), base.camera.copy(), np.array([0.55, 0.65, 0.8]))
+                   _cat(b.lights, A.LIGHT_DTYPE), camera, np.array([0.55, 0.65, 0.8]))
     return sc
 
 

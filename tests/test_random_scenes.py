@@ -17,7 +17,8 @@ CASES = [(11, {}), (12, {}), (13, dict(n_objects=90)), (14, dict(media=True)), (
          (19, dict(n_objects=200)), (20, dict(n_objects=40)), (21, dict(media=True, n_objects=12)),
          (22, dict(n_objects=3)), (23, dict(media=True, n_objects=100)), (24, dict(n_objects=60)),
          (25, dict(media=True)), (26, dict(n_objects=30, hollow=True)),
-         (27, dict(delta_lights=True)), (28, dict(delta_lights=True, media=True)), (29, dict(delta_lights=True, n_objects=70))]
+         (27, dict(delta_lights=True)), (28, dict(delta_lights=True, media=True)), (29, dict(delta_lights=True, n_objects=70)),
+         (30, dict(lens=0.12)), (31, dict(lens=0.05, media=True, n_objects=40))]
 
 
 def _bits(a):
