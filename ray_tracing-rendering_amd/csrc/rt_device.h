@@ -437,7 +437,7 @@ RT_DEV void wrapper_enter(int type, const double* f, V3& o, V3& d) {
 }
 
 /* defined below (order-free traversal of compiled sub-scenes) */
-template <bool ANY, bool TREES = true>
+template <bool ANY, bool TREES = true, bool WEXIT = ANY>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
                                            Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
                                            const Stack st, const int sp0);
@@ -704,7 +704,7 @@ RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real 
  * knows that no instance of the scene has a box tree and no reference is tie-capable (RT_TRAV_FLAT),
  * which keeps that code and its registers out of the kernels of small scenes (the Cornell box:
  * 118 VGPRs, no spills). */
-template <bool ANY, bool TREES>
+template <bool ANY, bool TREES, bool WEXIT>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
                                            Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
                                            const Stack st, const int sp0) {
@@ -734,7 +734,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
             const int r0 = I.ref_first, r1 = r0 + I.n_ref;
             for (int r = r0; r < r1; ++r) {
                 Real t;
-                if (fast_ref_hit<TREES, ANY>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
+                if (fast_ref_hit<TREES, WEXIT>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
                     tmax = t;
                     hit_ref = r;
                     hit_inst = ii;
@@ -773,7 +773,7 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                 const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
                 for (int r = r0; r < r1; ++r) {
                     Real t;
-                    if (fast_ref_hit<TREES, ANY>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
+                    if (fast_ref_hit<TREES, WEXIT>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
                         tmax = t;
                         tmax_f = float_above(t);
                         hit_ref = r;
@@ -866,7 +866,9 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
         for (int pass = 0; pass < passes; ++pass) {
             Real t = medium ? RT_INF : tmax;
             int r, i;
-            const bool h = trace_fast<false>(sc, sub.inst_first, sub.n_inst, o, d, time, lo, t, r, i, st, 0);
+            /* ANY = a shadow ray: closest hit all the same (a medium behind needs t_max), but its finite interval
+             * lets whole waves leave the rectangle tests early (rect_hit_axes) */
+            const bool h = trace_fast<false, true, ANY>(sc, sub.inst_first, sub.n_inst, o, d, time, lo, t, r, i, st, 0);
             if (!medium) {
                 if (h) tmax = t, ref = r, inst = i, med = -1, any = true;
             } else if (!h) {
