@@ -50,6 +50,11 @@ int rtr_test_reference_order(rtr_context* ctx, int on);
  * 16 bytes per lane are uncalibrated).  Returns RTR_OK or a negative status. */
 int rtr_test_stream8(rtr_context* ctx, int64_t n_doubles, int repeat);
 
+/* The samplers take sin and cos of phi = 2 pi r for r = s * 2^-32, s any state of the 32-bit generator
+ * (vec3.h:261-269, material.h:268-275); the device evaluates both with ONE sincos().  This walks ALL 2^32 values of
+ * s and counts those where sincos(phi) and the pair sin(phi), cos(phi) differ in any bit: *mismatches must be 0. */
+int rtr_test_sincos_exhaustive(rtr_context* ctx, uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,8 +122,12 @@ RT_DEV V3 random_cosine_direction(uint32_t& s) { /* vec3.h:261-269 */
     Real r2 = rng_next(s);
     Real z = __builtin_sqrt(1 - r2);
     Real phi = 2 * RT_PI * r1;
-    Real x = cos(phi) * __builtin_sqrt(r2);
-    Real y = sin(phi) * __builtin_sqrt(r2);
+    /* cos(phi) and sin(phi) from ONE sincos(): the same bits as the two calls for every phi = 2 pi s 2^-32 the
+     * generator can produce (rtr_test_sincos_exhaustive walks all 2^32 of them), one argument reduction less */
+    Real sphi, cphi;
+    sincos(phi, &sphi, &cphi);
+    Real x = cphi * __builtin_sqrt(r2);
+    Real y = sphi * __builtin_sqrt(r2);
     return mk(x, y, z);
 }
 
@@ -1197,7 +1201,9 @@ __device__ __forceinline__ bool pbr_sample(const MatCtx& c, V3 wo, BSDFSample& s
         Real phi = 2.0 * RT_PI * r1;
         Real cos_theta = __builtin_sqrt((1.0 - r2) / (1.0 + (a * a - 1.0) * r2));
         Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
-        V3 H_local = mk(sin_theta * cos(phi), sin_theta * sin(phi), cos_theta);
+        Real sphi, cphi; /* cos(phi), sin(phi) of material.h:272-274 from one argument reduction (see random_cosine_direction) */
+        sincos(phi, &sphi, &cphi);
+        V3 H_local = mk(sin_theta * cphi, sin_theta * sphi, cos_theta);
         V3 H = onb_local(uvw, H_local);
         V3 L = reflect(neg(wo), H);
         if (dot(N, L) <= 0) return false;

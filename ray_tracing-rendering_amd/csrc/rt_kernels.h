@@ -375,6 +375,20 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_li(const DScene sc, const Re
     recs[k] = r;
 }
 /* rtr_test_stream8: 8 bytes per lane in, 8 bytes per lane out */
+__global__ void __launch_bounds__(RTR_BLOCK) k_test_sincos(unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * RTR_BLOCK;
+    for (unsigned long long s = (unsigned long long)blockIdx.x * RTR_BLOCK + threadIdx.x; s < (1ull << 32); s += stride) {
+        const Real phi = 2.0 * RT_PI * ((uint32_t)s * 2.3283064365386963e-10); /* as random_cosine_direction / pbr_sample */
+        Real s2, c2;
+        sincos(phi, &s2, &c2);
+        const Real s1 = sin(phi), c1 = cos(phi);
+        bad += (__double_as_longlong(s1) != __double_as_longlong(s2)) | (__double_as_longlong(c1) != __double_as_longlong(c2));
+    }
+    bad = wave_sum(bad);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 __global__ void __launch_bounds__(RTR_BLOCK) k_stream8(const double* __restrict__ in, double* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * RTR_BLOCK)
         out[i] = in[i] + 1.0;

@@ -1155,6 +1155,23 @@ int rtr_test_stream8(rtr_context* c, int64_t n_doubles, int repeat) {
     return RTR_OK;
 }
 
+int rtr_test_sincos_exhaustive(rtr_context* c, uint64_t* mismatches) {
+    if (!c || !mismatches) return RTR_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = ensure(c, c->b_test, 8);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->b_test.p, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_test_sincos, dim3((unsigned)(c->n_cus * 16)), dim3(RTR_BLOCK), 0, c->stream,
+                       static_cast<unsigned long long*>(c->b_test.p));
+    HIPCHK(c, hipGetLastError());
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, c->b_test.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *mismatches = h;
+    return RTR_OK;
+}
+
 int rtr_li_samples(rtr_context* c, const rtr_render_params* p, const int32_t* ijs, double* L, int64_t n) {
     if (!c) return RTR_ERR_INVALID;
     if (n < 0 || (n > 0 && (!ijs || !L))) return fail(c, RTR_ERR_INVALID, "bad sample / radiance arrays");

@@ -21,7 +21,8 @@ _STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR
 EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
            "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_synchronize", "rtr_cancel",
            "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
-           "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order", "rtr_test_stream8")
+           "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order", "rtr_test_stream8",
+           "rtr_test_sincos_exhaustive")
 
 
 class SceneInfoC(C.Structure):
@@ -79,6 +80,7 @@ def lib():
     L.rtr_test_li.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
     L.rtr_test_reference_order.argtypes = [vp, C.c_int]
     L.rtr_test_stream8.argtypes = [vp, C.c_int64, C.c_int]
+    L.rtr_test_sincos_exhaustive.argtypes = [vp, C.POINTER(C.c_uint64)]
     if L.rtr_abi_version() != A.RTR_ABI_VERSION:
         raise RtrError(A.RTR_ERR_INVALID, "librtr_hip.so ABI version mismatch")
     _LIB = L
@@ -198,6 +200,12 @@ class Context:
     def stream8(self, n_doubles, repeat=1):
         """Counter calibration: stream n_doubles doubles in and out, 8 bytes per lane (include/rtr_hip_test.h)."""
         self._chk(self._L.rtr_test_stream8(self._h, int(n_doubles), int(repeat)))
+
+    def sincos_mismatches(self):
+        """All 2^32 sampler angles: how many give sincos(phi) != (sin(phi), cos(phi)) in some bit (include/rtr_hip_test.h)."""
+        n = C.c_uint64(0)
+        self._chk(self._L.rtr_test_sincos_exhaustive(self._h, C.byref(n)))
+        return int(n.value)
 
     # device unit kernels over golden-vector records (include/rtr_hip_test.h)
     def test_records(self, kind, recs, params=None):

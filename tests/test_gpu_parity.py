@@ -829,6 +829,12 @@ def test_large_flat_list(ctx, rtr):
     assert np.array_equal(_bits(dev["t"][h]), _bits(ora["t"][h]))
 
 
+def test_one_sincos_equals_sin_and_cos_on_every_sampler_angle(ctx):
+    """random_cosine_direction (vec3.h:261-269) and PBRMaterial::sample (material.h:268-275) call cos(phi) and
+    sin(phi); the device takes both from one sincos().  Exhaustive over the 2^32 states of the generator."""
+    assert ctx.sincos_mismatches() == 0
+
+
 def test_error_behaviour(ctx, rtr):
     sc = _upload(ctx, 21)
     with pytest.raises(rtr.RtrError) as e:
