@@ -282,6 +282,11 @@ struct Stack {
 #define RT_FRAME_TRANSLATE 8 /* o.xyz (6) + hits + marker */
 #define RT_FRAME_ROTATE 14   /* o.x o.z d.x d.z inv.x inv.z (12) + hits + marker */
 #define RT_FRAME_FLIP 2      /* hits + marker */
+/* a hittable_list with more than RT_LIST_BULK children is walked through a two-word continuation (next child
+ * index + marker) instead of one stack word per child: the stack then grows with the depth of the graph, not
+ * with the length of a flat list (a world of hundreds of objects without a bvh_node around it) */
+#define RT_LIST_BULK 8
+#define RT_LIST_MARK 0x40000000 /* stack word: continuation of list node (word & ~RT_LIST_MARK); node indices stay below */
 
 /* geometry/aabb.h:31-48 with ray.h's cached inv_dir / dir_sign */
 RT_DEV bool aabb_hit(const double* b, V3 o, V3 inv, Real t_min, Real t_max) {
@@ -483,6 +488,17 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
             }
             continue;
         }
+        if (e >= RT_LIST_MARK) { /* next child of a long hittable_list (hittable_list.h:38-44: in order) */
+            const int list = e & ~RT_LIST_MARK;
+            const rtr_node ln = ld_const(sc.nodes, list);
+            const int k = st.get(--sp);
+            if (k + 1 < ln.b) {
+                st.put(sp++, k + 1);
+                st.put(sp++, e);
+            }
+            st.put(sp++, as_const(sc.list_children)[ln.a + k]);
+            continue;
+        }
         const rtr_node n = ld_const(sc.nodes, e);
         const int type = n.type;
         if (type == RTR_NODE_BVH) {
@@ -507,7 +523,12 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
                 if (FULL) sphere_fill(n, type, center, radius, o, d, t, sc.needs_uv != 0, rec);
             }
         } else if (type == RTR_NODE_LIST) {
-            for (int k = n.b - 1; k >= 0; --k) st.put(sp++, as_const(sc.list_children)[n.a + k]);
+            if (n.b > RT_LIST_BULK) {
+                st.put(sp++, 0);
+                st.put(sp++, e | RT_LIST_MARK);
+            } else {
+                for (int k = n.b - 1; k >= 0; --k) st.put(sp++, as_const(sc.list_children)[n.a + k]);
+            }
         } else if (type == RTR_NODE_TRANSLATE) { /* geometry/hittable.h:51-56 */
             st.putd(sp, o.x), st.putd(sp + 2, o.y), st.putd(sp + 4, o.z);
             sp += 6;

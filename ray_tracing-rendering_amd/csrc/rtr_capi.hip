@@ -247,8 +247,13 @@ struct Validator {
             switch (n.type) {
             case RTR_NODE_BVH: u = std::max(2, std::max(1 + need[n.a], need[n.b])); break;
             case RTR_NODE_LIST:
-                u = m;
-                for (int k = 0; k < m; ++k) u = std::max(u, (m - 1 - k) + need[child_at(n, k)]);
+                if (m > RT_LIST_BULK) { /* continuation (2 words) + the child being walked */
+                    u = 3;
+                    for (int k = 0; k < m; ++k) u = std::max(u, 2 + need[child_at(n, k)]);
+                } else {
+                    u = m;
+                    for (int k = 0; k < m; ++k) u = std::max(u, (m - 1 - k) + need[child_at(n, k)]);
+                }
                 break;
             case RTR_NODE_TRANSLATE: u = RT_FRAME_TRANSLATE + std::max(1, need[n.a]); break;
             case RTR_NODE_ROTATE_Y: u = RT_FRAME_ROTATE + std::max(1, need[n.a]); break;
@@ -272,7 +277,8 @@ struct Validator {
     int run(rtr_scene_info* info) {
         if (!s) return (bad(RTR_ERR_INVALID, "null scene"), code);
         if (s->abi_version != RTR_ABI_VERSION) return (bad(RTR_ERR_INVALID, "ABI version mismatch"), code);
-        if (s->n_nodes <= 0 || s->n_list_children < 0 || s->n_materials < 0 || s->n_textures < 0 ||
+        if (s->n_nodes >= RT_LIST_MARK) return (bad(RTR_ERR_INVALID, "more than 2^30 nodes"), code);
+    if (s->n_nodes <= 0 || s->n_list_children < 0 || s->n_materials < 0 || s->n_textures < 0 ||
             s->n_perlin < 0 || s->n_images < 0 || s->n_lights < 0)
             return (bad(RTR_ERR_INVALID, "negative or empty counts"), code);
         if (!node_ix(s->root)) return (bad(RTR_ERR_INVALID, "root out of range"), code);

@@ -71,9 +71,9 @@ def test_hollow_spheres_keep_the_reference_walk(sid, inverted):
 
 
 def test_large_flat_list_compiles():
-    """A hittable_list with 50 000 direct children (no bvh_node around it): the reference-order walk would
-    need a 50 000-word stack per lane, the compiled traversal a box tree of depth ~16 -- upload must
-    accept the scene (the LDS limit is checked per traversal at launch) and compile it in linear-ish time."""
+    """A hittable_list with 50 000 direct children (no bvh_node around it): the compiled traversal builds a box
+    tree of depth ~16 over them, and the reference-order walk steps through a long list with a two-word
+    continuation instead of one stack word per child -- neither needs an LDS stack that grows with the list."""
     base = G.scene(23)
     n = 50_000
     rng = np.random.default_rng(3)
@@ -86,8 +86,10 @@ def test_large_flat_list_compiles():
     sc = rtr.Scene(0, nodes, np.arange(1, n + 1, dtype=np.int32), base.materials, base.textures, base.perlin,
                    base.images, base.image_bytes, base.lights, base.camera, base.background)
     info = rtr.native.validate_scene(sc)
-    assert info["fast_ok"] and info["fast_refs"] == n and info["stack_words"] == n
+    assert info["fast_ok"] and info["fast_refs"] == n and info["stack_words"] == 3
     assert 8 <= info["fast_stack_words"] <= 40
+    # a short list still takes one word per child (a box: six)
+    assert rtr.native.validate_scene(G.scene(1006))["stack_words"] == 6
 
 
 def _mutated(sid, fn):

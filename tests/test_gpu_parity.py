@@ -797,9 +797,9 @@ def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
 
 
 def test_large_flat_list(ctx, rtr):
-    """50 000 spheres as direct children of one hittable_list: the compiled traversal renders it (box tree),
-    the reference-order walk would need a 50 000-word LDS stack per lane and is refused loudly; a random
-    subset of the rays is checked against the oracle's brute-force reference-order answer."""
+    """50 000 spheres as direct children of one hittable_list: the compiled traversal renders it through a box
+    tree; the reference-order walk steps through the list with a two-word continuation (not one LDS stack word
+    per child) and gives the same bits by brute force; rays are checked against the oracle as well."""
     base = G.scene(23)
     n = 50_000
     rng = np.random.default_rng(3)
@@ -814,19 +814,22 @@ def test_large_flat_list(ctx, rtr):
     ctx.upload(sc)
     out = ctx.render(A.make_params(96, 54, 4, integrator=4, seed=2))
     assert np.isfinite(out).all() and out.mean() > 0
-    with pytest.raises(rtr.RtrError) as e:
-        ctx.render(A.make_params(96, 54, 1, integrator=4, seed=2, flags=A.FLAG_REFERENCE_ORDER))
-    assert e.value.code == A.RTR_ERR_UNSUPPORTED
+    small = ctx.render(A.make_params(32, 18, 2, integrator=4, seed=2))
+    brute = ctx.render(A.make_params(32, 18, 2, integrator=4, seed=2, flags=A.FLAG_REFERENCE_ORDER))
+    assert np.array_equal(_bits(small), _bits(brute))
     rays = np.zeros(256, dtype=A.HIT_DTYPE)
     rays["o"] = rng.uniform(-6.0, 6.0, (256, 3))
     rays["d"] = rng.normal(0.0, 1.0, (256, 3))
     rays["t_min"], rays["t_max"], rays["rng_in"] = 0.001, np.inf, 9
-    dev = ctx.test_records("hits", rays)
     ora = G.oracle_records(sc, "rto_hits", rays)
-    assert dev["hit"].sum() > 20 and np.array_equal(dev["hit"], ora["hit"])
     h = ora["hit"] == 1
-    assert np.array_equal(dev["material"][h], ora["material"][h])
-    assert np.array_equal(_bits(dev["t"][h]), _bits(ora["t"][h]))
+    for ref_order in (False, True):
+        ctx.reference_order(ref_order)
+        dev = ctx.test_records("hits", rays)
+        ctx.reference_order(False)
+        assert dev["hit"].sum() > 20 and np.array_equal(dev["hit"], ora["hit"]), ref_order
+        assert np.array_equal(dev["material"][h], ora["material"][h]), ref_order
+        assert np.array_equal(_bits(dev["t"][h]), _bits(ora["t"][h])), ref_order
 
 
 def test_one_sincos_equals_sin_and_cos_on_every_sampler_angle(ctx):

@@ -61,13 +61,8 @@ def test_random_scene_hit_records_equal_the_oracle(ctx, seed, kw):
     moving = np.isin(ora["material"], sc.nodes["a"][sc.nodes["type"] == A.NODE_MOVING_SPHERE])
     for exact_order in (False, True):
         ctx.reference_order(exact_order)
-        try:
-            dev = ctx.test_records("hits", rays)
-        except rtr.RtrError as e:  # one LDS stack word per direct child of a flat list: 160 KiB end at ~150 of them
-            assert exact_order and e.code == A.RTR_ERR_UNSUPPORTED and rtr.native.validate_scene(sc)["stack_words"] > 150, e
-            continue
-        finally:
-            ctx.reference_order(False)
+        dev = ctx.test_records("hits", rays)
+        ctx.reference_order(False)
         tag = "random%02d.%s" % (seed, "reference_order" if exact_order else "compiled")
         assert np.array_equal(dev["hit"], ora["hit"]), tag
         for f in ("front_face", "material", "rng_out"):
@@ -101,13 +96,7 @@ def test_random_scene_renders_equal_the_oracle(ctx, seed, kw):
         if wavefront:
             runs.append((A.PIPELINE_WAVEFRONT, 0))
         for pipe, flags in runs:
-            try:
-                got = ctx.render(A.make_params(48, 32, 4, integrator=integ, seed=100 + seed, pipeline=pipe, flags=flags))
-            except rtr.RtrError as e:
-                # the reference-order walk keeps one stack word per direct child of a hittable_list in LDS: a flat
-                # list of 120 objects plus the parked path state of the light-sampling integrators is over 160 KiB
-                assert flags == A.FLAG_REFERENCE_ORDER and e.code == A.RTR_ERR_UNSUPPORTED and info["stack_words"] > 100, (seed, integ, pipe, flags, e)
-                continue
+            got = ctx.render(A.make_params(48, 32, 4, integrator=integ, seed=100 + seed, pipeline=pipe, flags=flags))
             st = ctx.stats()
             tag = "random%02d.i%d.pipe%d.flags%d" % (seed, integ, pipe, flags)
             assert st["closest_segments"] == wst["closest_segments"] and st["shadow_segments"] == wst["shadow_segments"], tag
