@@ -133,7 +133,7 @@ def _cat(parts, dtype):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=dtype)
 
 
-def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta_lights=False, lens=0.0):
+def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta_lights=False, lens=0.0, moved_media=False):
     """One scene in front of scene 23's camera (origin (0,3,8), looking at the origin)."""
     rng = np.random.default_rng(seed)
     b = Builder(rng)
@@ -205,6 +205,10 @@ def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta
         top.append(b.medium(b.sphere([0.0, 0.0, 0.0], 40.0, ground), 0.01, [1.0, 1.0, 1.0]))  # mist around everything
         order = rng.permutation(len(top))  # media anywhere in the visiting order, not only at its end
         top = [top[i] for i in order]
+    if moved_media:  # a medium UNDER a transform (scenes.cpp:214-217: cornell_smoke's boxes): no step program for it
+        smoke = b.medium(b.box([0.0, 0.0, 0.0], [1.2, 1.6, 1.1], ground), 1.2, [0.1, 0.1, 0.1])
+        top.insert(len(top) // 2, b.translate(b.rotate_y(smoke, 25.0), pos()))
+        top.insert(len(top) // 3, b.translate(b.medium(b.sphere([0.0, 0.0, 0.0], 0.8, ground), 2.0, [0.9, 0.8, 0.7]), pos()))
     root = b.hlist(top)
     camera = base.camera.copy()
     camera["lens_radius"] = lens  # camera.h:33-39: the defocus disk is drawn for every ray, used when the lens is open

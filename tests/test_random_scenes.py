@@ -18,7 +18,8 @@ CASES = [(11, {}), (12, {}), (13, dict(n_objects=90)), (14, dict(media=True)), (
          (22, dict(n_objects=3)), (23, dict(media=True, n_objects=100)), (24, dict(n_objects=60)),
          (25, dict(media=True)), (26, dict(n_objects=30, hollow=True)),
          (27, dict(delta_lights=True)), (28, dict(delta_lights=True, media=True)), (29, dict(delta_lights=True, n_objects=70)),
-         (30, dict(lens=0.12)), (31, dict(lens=0.05, media=True, n_objects=40))]
+         (30, dict(lens=0.12)), (31, dict(lens=0.05, media=True, n_objects=40)),
+         (32, dict(moved_media=True)), (33, dict(moved_media=True, media=True, n_objects=50))]
 
 
 def _bits(a):
@@ -30,11 +31,13 @@ def test_random_scenes_validate_and_run_on_the_oracle(seed, kw):
     """CPU: the generator's scenes are well-formed and the oracle traces them (no GPU)."""
     sc = R.random_scene(seed, **kw)
     info = rtr.native.validate_scene(sc)
-    assert info["has_media"] == bool(kw.get("media")) and info["inverted_boxes"] == (1 if kw.get("hollow") else 0)
-    if not kw.get("media") and not kw.get("hollow"):
+    assert info["has_media"] == bool(kw.get("media") or kw.get("moved_media")) and info["inverted_boxes"] == (1 if kw.get("hollow") else 0)
+    if not kw.get("media") and not kw.get("hollow") and not kw.get("moved_media"):
         assert info["fast_ok"] and info["fast_refs"] >= 3
-    if kw.get("media") and not kw.get("hollow"):
+    if kw.get("media") and not kw.get("hollow") and not kw.get("moved_media"):
         assert info["program_steps"] >= 4  # media under lists only: the step program exists
+    if kw.get("moved_media"):
+        assert info["program_steps"] == 0  # a medium under a transform: the reference-order walk stays in charge
     rays = R.random_rays(seed, 500)
     out = G.oracle_records(sc, "rto_hits", rays)
     assert 50 < int(out["hit"].sum()) <= 500
