@@ -573,6 +573,11 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
             }
             FStep st{};
             st.kind = 1, st.sub = sub, st.mat = n.b, st.neg_inv_density = n.f[0];
+            const rtr_node& bn = scene->nodes[n.a];
+            const FSub& bs = cs.subs[sub];
+            if (bn.type == RTR_NODE_SPHERE && bn.f[3] > 0 && bs.n_inst == 1 && cs.inst[bs.inst_first].n_xf == 0 &&
+                cs.inst[bs.inst_first].n_ref == 1 && cs.inst[bs.inst_first].bvh_root < 0)
+                st.kind = 2, st.pad = cs.inst[bs.inst_first].ref_first;
             cs.steps.push_back(st);
             cs.step_tail = (int)cs.steps.size();
         }

@@ -247,7 +247,8 @@ struct FSub {
  * the last bit (tests/: program == reference-order walk on every golden scene).  All lanes of a
  * wave run the same steps; there is no per-node interpretation left on this path. */
 struct FStep {
-    int32_t kind; /* 0: geometry sub-scene `sub`; 1: constant_medium with boundary sub-scene `sub` */
+    int32_t kind; /* 0: geometry sub-scene `sub`; 1: constant_medium with boundary sub-scene `sub`; 2: constant_medium whose
+                   * boundary is one plain sphere in the world frame, reference `pad` (run_program's short cut; `sub` as for 1) */
     int32_t sub;
     int32_t mat;  /* medium: phase function material */
     int32_t pad;
@@ -882,6 +883,35 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
         /* a shadow ray that is blocked may stop once no medium is left to draw */
         if (ANY && any && k >= sc.fstep_tail) break;
         const FStep step = ld_const(sc.fstep, k);
+        /* constant_medium.h:68-103 once both boundary hits exist: clip to the ray's interval, draw, scatter or not */
+        auto medium_between = [&](Real t1, Real t2) {
+            if (t1 < tmin) t1 = tmin;
+            if (t2 > tmax) t2 = tmax;
+            if (!(t1 >= t2)) {
+                if (t1 < 0) t1 = 0;
+                const Real ray_length = len(d);
+                const Real distance_inside_boundary = (t2 - t1) * ray_length;
+                const Real hit_distance = step.neg_inv_density * log(rng_next(rng));
+                if (!(hit_distance > distance_inside_boundary)) {
+                    tmax = t1 + hit_distance / ray_length;
+                    med = k, any = true;
+                }
+            }
+        };
+        if (step.kind == 2) {
+            /* the boundary is ONE plain sphere in the world frame (the fog ball and the mist around everything
+             * in final_scene): both boundary->hit calls (constant_medium.h:62-66) side by side, so the
+             * discriminant, its root and the near root of sphere::hit are computed once -- the same operations on
+             * the same operands, shared by the optimiser, instead of two rounds through the generic cast */
+            const rtr_node n = ld_const(sc.fprim, step.pad);
+            const V3 center = ld3(n.f);
+            const Real radius = n.f[3];
+            Real t1, t2;
+            if (sphere_hit_t(center, radius, o, d, -RT_INF, RT_INF, t1) &&
+                sphere_hit_t(center, radius, o, d, t1 + 0.0001, RT_INF, t2))
+                medium_between(t1, t2);
+            continue;
+        }
         const FSub sub = ld_const(sc.fsub, step.sub);
         const bool medium = step.kind != 0;
         Real lo = medium ? -RT_INF : tmin;
@@ -901,20 +931,8 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
             } else if (pass == 0) {
                 t1 = t;
                 lo = t + 0.0001;
-            } else { /* constant_medium.h:68-103 */
-                Real t2 = t;
-                if (t1 < tmin) t1 = tmin;
-                if (t2 > tmax) t2 = tmax;
-                if (!(t1 >= t2)) {
-                    if (t1 < 0) t1 = 0;
-                    const Real ray_length = len(d);
-                    const Real distance_inside_boundary = (t2 - t1) * ray_length;
-                    const Real hit_distance = step.neg_inv_density * log(rng_next(rng));
-                    if (!(hit_distance > distance_inside_boundary)) {
-                        tmax = t1 + hit_distance / ray_length;
-                        med = k, any = true;
-                    }
-                }
+            } else {
+                medium_between(t1, t);
             }
         }
     }
