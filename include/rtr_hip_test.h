@@ -55,6 +55,11 @@ int rtr_test_stream8(rtr_context* ctx, int64_t n_doubles, int repeat);
  * s and counts those where sincos(phi) and the pair sin(phi), cos(phi) differ in any bit: *mismatches must be 0. */
 int rtr_test_sincos_exhaustive(rtr_context* ctx, uint64_t* mismatches);
 
+/* The primitive tests divide many numerators by the same ray-direction component through a shared refined reciprocal
+ * (rt_device.h: div_shared) instead of the compiler's eleven-instruction division.  This compares the two on 2^32
+ * operand pairs from the range the short form is used in; *mismatches (quotients that differ in any bit) must be 0. */
+int rtr_test_shared_division(rtr_context* ctx, uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

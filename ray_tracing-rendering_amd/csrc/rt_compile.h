@@ -27,6 +27,7 @@ struct CompiledScene {
     std::vector<FRef> ref;
     std::vector<int32_t> exits;
     std::vector<FBvh> bvh;
+    std::vector<double> scan; /* packed geometry of the linearly scanned instances (FInst::scan_first / run) */
     std::vector<FStep> steps; /* ray-cast program of a scene with media (empty: none could be built) */
     int step_tail = 0;
     int stack_words = 1;
@@ -34,6 +35,11 @@ struct CompiledScene {
 };
 
 namespace rtc {
+
+/* FInst::scan_first / run[] of every linearly scanned instance; `prims` = the per-reference node records with their tie
+ * flags (rtr_upload_scene).  Instances whose references do not fit RT_INST_RUNS_MAX runs, or that hold a tie-capable
+ * reference (its visiting position takes part in the test), keep the generic loop. */
+inline void build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>& prims);
 
 constexpr int kLinearMax = 12; /* instances with more references get a box tree */
 constexpr int kLeafMax = 4;
@@ -382,6 +388,15 @@ struct Builder {
                 I.bound = float_up(bound);
                 stack = std::max(stack, depth + 2);
             }
+            I.flags = 0;
+            for (int k = 0; k < I.n_xf; ++k)
+                if (out.xf[I.xf_first + k].type == RTR_NODE_ROTATE_Y) I.flags |= RT_INST_ROTATED;
+            for (int k = 0; k < RT_INST_XF_INLINE; ++k) {
+                I.xf_type[k] = k < I.n_xf ? out.xf[I.xf_first + k].type : 0;
+                for (int c = 0; c < 3; ++c) I.xf_f[k][c] = k < I.n_xf ? out.xf[I.xf_first + k].f[c] : 0.0;
+            }
+            for (const PendingRef& r : refs)
+                if (s->nodes[r.node].type < RTR_NODE_XY_RECT) I.flags |= RT_INST_SPHERES;
             Box local;
             for (const PendingRef& r : refs) {
                 FRef fr{};
@@ -591,4 +606,33 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
         }
     }
     return cs;
+}
+
+inline void rtc::build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>& prims) {
+    cs.scan.clear();
+    for (FInst& I : cs.inst) {
+        I.flags &= ~RT_INST_RUNS;
+        I.scan_first = 0;
+        I.runs = 0;
+        if (I.bvh_root >= 0 || I.n_ref == 0) continue;
+        std::vector<std::pair<int, int>> runs; /* type, count */
+        bool ok = true;
+        for (int r = I.ref_first; r < I.ref_first + I.n_ref && ok; ++r) {
+            const rtr_node& n = prims[r];
+            if (n.reserved & RT_TIE_FLAG) ok = false;
+            if (runs.empty() || runs.back().first != n.type || runs.back().second == 127) runs.push_back({n.type, 0});
+            ++runs.back().second;
+        }
+        if (!ok || (int)runs.size() > RT_INST_RUNS_MAX) continue;
+        I.scan_first = (int32_t)cs.scan.size();
+        for (size_t k = 0; k < runs.size(); ++k)
+            I.runs |= (uint64_t)((runs[k].first - RTR_NODE_SPHERE) << 7 | runs[k].second) << (10 * k);
+        for (int r = I.ref_first; r < I.ref_first + I.n_ref; ++r) {
+            const rtr_node& n = prims[r];
+            const int nf = n.type == RTR_NODE_SPHERE ? 4 : (n.type == RTR_NODE_MOVING_SPHERE ? 9 : 5);
+            cs.scan.insert(cs.scan.end(), n.f, n.f + nf);
+        }
+        I.flags |= RT_INST_RUNS;
+    }
+    cs.scan.resize(cs.scan.size() + 16, 0.0); /* the two-records-per-trip loads never leave the array */
 }

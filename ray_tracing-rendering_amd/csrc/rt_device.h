@@ -29,6 +29,37 @@
 
 typedef double Real;
 
+/* ---- region profile (debug builds: -DRTR_REGION_PROFILE; tools/region_profile.sh) ---------------------------------
+ * Where a wave's cycles go: every marker charges the shader cycles (s_memtime) since the wave's previous marker to
+ * the region that was current, then makes `id` current.  Counters live in LDS per wave and are added to
+ * RenderK::stats[RT_PROF_BASE ...] when the workgroup ends.  The markers cost about a tenth of the wave's time
+ * themselves: read the table as proportions.  In product builds RT_REGION() expands to nothing. */
+#define RT_STATS_WORDS 80 /* u64 words of RenderK::stats: 8 of the product + 2 x 32 region words */
+#define RT_PROF_BASE 8
+#define RT_PROF_REGIONS 32
+enum { RG_OTHER = 0, RG_SETUP = 1, RG_RECTS = 2, RG_SPHERES = 3, RG_GENERIC = 4, RG_TREE = 5, RG_LEAVES = 6, RG_FINISH = 7,
+       RG_SH_SETUP = 8, RG_SH_RECTS = 9, RG_SH_SPHERES = 10, RG_SH_GENERIC = 11, RG_SH_TREE = 12, RG_SH_LEAVES = 13,
+       RG_MEDIA = 14, RG_MATPREP = 15, RG_SHADE_A = 16, RG_SHADE_B = 17, RG_MISS = 18, RG_REGEN = 19, RG_SHADE_RR = 20,
+       RG_PARK = 21, RG_N = 22 };
+#ifdef RTR_REGION_PROFILE
+__shared__ unsigned long long rt_prof_lds[4 * 2 * RT_PROF_REGIONS + 4 * 2]; /* [wave][cycles | visits][region], then [wave][last, current] */
+RT_DEV void rt_region(int id) {
+    const unsigned long long m = __ballot(1);
+    if ((int)__lane_id() == __builtin_ctzll(m)) {
+        const int w = threadIdx.x >> 6;
+        unsigned long long* acc = rt_prof_lds + w * 2 * RT_PROF_REGIONS;
+        unsigned long long* st = rt_prof_lds + 4 * 2 * RT_PROF_REGIONS + w * 2;
+        const unsigned long long now = __builtin_readcyclecounter();
+        acc[st[1]] += now - st[0];
+        acc[RT_PROF_REGIONS + id] += 1;
+        st[0] = now, st[1] = (unsigned long long)id;
+    }
+}
+#define RT_REGION(id) rt_region(id)
+#else
+#define RT_REGION(id) do { } while (0)
+#endif
+
 #define RT_INF (__builtin_huge_val())
 #define RT_PI 3.1415926535897932385 /* core/rtweekend.h:18 */
 
@@ -131,6 +162,80 @@ RT_DEV V3 random_cosine_direction(uint32_t& s) { /* vec3.h:261-269 */
     return mk(x, y, z);
 }
 
+/* ---- IEEE division with a shared divisor ------------------------------------------------------
+ * hipcc expands a double division n / d into eleven VALU instructions:
+ *     ds = v_div_scale(d), ns = v_div_scale(n), r0 = v_rcp_f64(ds),
+ *     r1 = fma(r0, fma(-ds, r0, 1), r0), r2 = fma(r1, fma(-ds, r1, 1), r1),        <- depends on d only
+ *     q0 = ns * r2, q1 = v_div_fmas(fma(-ds, q0, ns), r2, q0), v_div_fixup(q1, d, n)
+ * v_div_scale returns its operand unchanged, v_div_fmas is a plain fma and v_div_fixup returns q1 unless an
+ * operand is zero / inf / NaN / denormal or the exponents are extreme (difference >= 768, |n| < 2^-969,
+ * |d| > 2^1021, |n / d| < 2^-1022).  A ray divides many numerators by the same few numbers -- the three
+ * components of its direction (x?_rect::hit: t = (k - o) / d, aarect.h:80,99,118) and |d|^2 (sphere::hit:
+ * root = (-half_b -+ sqrtd) / a, sphere.h:43-47) -- so r2 is computed once per ray and frame and a division costs
+ * the last three instructions.  While |d| is in [2^-100, 2^100], |n| in [2^-300, 2^200] that IS the compiler's
+ * sequence, operand for operand: the same bits as n / d (tests/: rtr_test_shared_division on 2^32 pairs).
+ * Outside: an unsafe divisor (or a ray origin beyond 2^80, which bounds n) switches the whole wave to plain
+ * divisions (`fast`, wave-uniform); a numerator below 2^-300 (zero included: the sign of a zero quotient) gives a
+ * quotient below 2^-200 either way, which every caller with t_min >= 2^-100 rejects by `t < t_min` -- the
+ * others (medium boundaries: t_min = -inf) take the plain division for such numerators (`guard`). */
+RT_DEV Real rcp_refined(Real d) {
+    Real r = __builtin_amdgcn_rcp(d);
+    Real e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+RT_DEV bool rcp_safe(Real d) { return (__builtin_fabs(d) >= 0x1p-100) & (__builtin_fabs(d) <= 0x1p100); }
+/* n / d given r = rcp_refined(d).  SHARED is decided once per ray and frame (RayDiv::fast, wave-uniform), outside the
+ * loops over primitives: every instruction counts in them, a scalar branch as much as an FP64 one */
+template <bool SHARED>
+RT_DEV Real div_shared(Real n, Real d, Real r, bool guard) {
+    if (!SHARED) return n / d;
+    const Real q = n * r;
+    const Real e = __builtin_fma(-d, q, n);
+    Real t = __builtin_fma(e, r, q);
+    if (guard && !(__builtin_fabs(n) >= 0x1p-300)) t = n / d;
+    return t;
+}
+/* what the primitive tests of one ray in one frame share */
+struct RayDiv {
+    Real rx, ry, rz; /* rcp_refined of the direction's components */
+    Real a, ra;      /* |d|^2 and its refined reciprocal (frames that hold spheres) */
+    bool fast;       /* wave-uniform: every lane's direction components (and a, where the frame holds spheres), origin and
+                        interval allow div_shared's short form */
+    bool guard;      /* t_min < 2^-100: tiny numerators take the plain division */
+};
+RT_DEV RayDiv raydiv_none() {
+    RayDiv q;
+    q.rx = q.ry = q.rz = q.a = q.ra = 0;
+    q.fast = q.guard = false;
+    return q;
+}
+/* every lane's origin is small enough for div_shared's numerators (checked once per cast, in the world frame: the
+ * transforms of a chain add scene coordinates below 2^60 to it at most 30 times) */
+RT_DEV bool raydiv_origin_ok(V3 o) {
+    return __all((__builtin_fabs(o.x) <= 0x1p80) & (__builtin_fabs(o.y) <= 0x1p80) & (__builtin_fabs(o.z) <= 0x1p80));
+}
+/* one frame of a cast; `origin_ok` = raydiv_origin_ok of the world ray and DScene::shared_div */
+RT_DEV RayDiv raydiv_make(V3 d, Real tmin, bool origin_ok) {
+    RayDiv q;
+    q.rx = rcp_refined(d.x), q.ry = rcp_refined(d.y), q.rz = rcp_refined(d.z);
+    q.a = q.ra = 0;
+    q.guard = !(tmin >= 0x1p-100);
+    q.fast = origin_ok && __all(rcp_safe(d.x) & rcp_safe(d.y) & rcp_safe(d.z));
+    return q;
+}
+RT_DEV void raydiv_spheres(RayDiv& q, V3 d) {
+    q.a = len2(d);
+    q.ra = rcp_refined(q.a);
+    q.fast = q.fast && __all(rcp_safe(q.a));
+}
+/* 1 / d for the conservative box tests: the refined reciprocal is within an ulp of it */
+RT_DEV V3 raydiv_inv(const RayDiv& q, V3 d) {
+    if (q.fast) return mk(q.rx, q.ry, q.rz);
+    return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+}
+
 /* ---- device scene ------------------------------------------------------------------------ */
 /* Scene arrays are immutable during a render.  Reading them through the constant address space
  * tells the compiler so: wave-uniform accesses (instance / reference / primitive loops of the
@@ -168,11 +273,15 @@ struct DScene {
     int32_t n_nodes;
     int32_t n_lights;
     int32_t needs_uv; /* some texture reads (u,v): image textures */
+    int32_t shared_div; /* every coordinate of the scene is below 2^60 and no transform chain is deeper than 30: the primitive
+                           tests may divide through RayDiv (div_shared's range argument) */
+    int32_t pad_;
     /* compiled scene for the order-free traversal (trace_fast); scenes with media use it per step (FStep) */
     const struct FInst* finst;
     const struct FXf* fxf;
     const struct FRef* fref;
     const rtr_node* fprim; /* copy of the primitive's node record per reference (one load hop less) */
+    const double* fscan;   /* packed geometry of linearly scanned references (see FInst) */
     const int32_t* fexit;
     const struct FBvh* fbvh;
     const struct FSub* fsub; /* compiled sub-scenes: [0] = whole scene when it has no media */
@@ -202,13 +311,36 @@ struct FInst {
     int32_t ref_first, n_ref;
     int32_t bvh_root;        /* -1: scan the references linearly */
     float bound;             /* box tree: largest |coordinate| of any of its boxes (instance frame) */
-    int32_t pad[2];
+    int32_t flags;           /* RT_INST_* */
+    /* Packed scan records of a linearly scanned instance (bvh_root < 0): its references in visiting order, cut into
+     * runs of one primitive type, the geometry of each reference as bare doubles in DScene::fscan from `scan_first` on
+     * -- x?_rect: a0 a1 b0 b1 k (aarect.h:31,53,75), sphere: centre radius, moving_sphere: c0 c1 t0 t1 radius.  A
+     * run's loop knows its type at compile time and fetches two records per trip through one scalar-load round trip.
+     * `runs` holds up to six runs of ten bits each, first run lowest: (type - RTR_NODE_SPHERE) << 7 | count, 0 ends
+     * the list (one scalar register pair: shifting it out needs no indexed access to this record).  Instances with
+     * more runs than fit, or with tie-capable references, keep the generic loop over fprim (RT_INST_RUNS clear). */
+    int32_t scan_first;
+    int32_t pad;
+    uint64_t runs;
+    /* the first two transform ops of the chain, inline (a copy of fxf[xf_first ...]): translate(rotate_y(...)) of the
+     * reference's scenes comes in with the record itself instead of through two more dependent loads */
+    int32_t xf_type[2];
+    double xf_f[2][3];
 };
+#define RT_INST_RUNS_MAX 6
+#define RT_INST_XF_INLINE 2
+#define RT_INST_ROTATED 1 /* a rotate_y in the chain: the direction's x and z differ from the frame above */
+#define RT_INST_SPHERES 2 /* holds sphere / moving_sphere references: the frame needs |d|^2 and its reciprocal */
+#define RT_INST_RUNS 4    /* scan_first / run[] describe the references (see FInst) */
 struct FXf {
     int32_t type; /* RTR_NODE_TRANSLATE (f = offset) or RTR_NODE_ROTATE_Y (f[0] = sin, f[1] = cos) */
     int32_t pad;
     double f[3];
 };
+/* fprim[ref].f[9] carries, as an integer's bits, the wrappers the reference sits under, innermost first, two bits
+ * each: 1 = the next translate / rotate_y of its instance's chain (from the inside), 2 = flip_face, 0 = end;
+ * RT_EXIT_LONG in place of it all = more than 31 wrappers or a moving_sphere-sized record: use the FRef list. */
+#define RT_EXIT_LONG (~0ull)
 struct FRef {
     int32_t node;       /* primitive node index */
     int32_t exit_first; /* into fexit: wrapper node indices, innermost first */
@@ -333,12 +465,12 @@ RT_DEV void sphere_uv(V3 p, Real& u, Real& v) { /* geometry/sphere.h:24-30 */
 
 /* ---- primitive tests shared by both traversals ------------------------------------------------ */
 /* x?_rect::hit (geometry/aarect.h:79-135): t and the in-plane coordinates (a, b) */
-template <bool WAVE_EXIT = false>
-RT_DEV bool rect_hit_axes(const rtr_node& n, Real ok, Real dk, Real oa, Real da, Real ob, Real db, Real tmin, Real tmax,
-                          Real& t, Real& a, Real& b) {
+template <bool WAVE_EXIT = false, bool SHARED = false>
+RT_DEV bool rect_hit_axes(const rtr_node& n, Real ok, Real dk, Real rk, const RayDiv& q, Real oa, Real da, Real ob, Real db,
+                          Real tmin, Real tmax, Real& t, Real& a, Real& b) {
     /* same tests as aarect.h:80-88 (a NaN fails none of the rejects there, nor here), evaluated
      * without per-lane early exits: lanes of a wave diverge on them anyway */
-    t = (n.f[4] - ok) / dk;
+    t = div_shared<SHARED>(n.f[4] - ok, dk, rk, q.guard);
     const bool off = (t < tmin) | (t > tmax);
     /* WAVE_EXIT (shadow rays): the one exit that costs no divergence -- no lane of the wave reaches the plane
      * inside its interval, e.g. every shadow ray against the walls of the room it starts in */
@@ -348,21 +480,22 @@ RT_DEV bool rect_hit_axes(const rtr_node& n, Real ok, Real dk, Real oa, Real da,
     const bool out = off | (a < n.f[0]) | (a > n.f[1]) | (b < n.f[2]) | (b > n.f[3]);
     return !out;
 }
-template <bool WAVE_EXIT = false>
-RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, Real tmin, Real tmax, Real& t, Real& a, Real& b) {
+template <bool WAVE_EXIT = false, bool SHARED = false>
+RT_DEV bool rect_hit_t(const rtr_node& n, int type, V3 o, V3 d, const RayDiv& q, Real tmin, Real tmax, Real& t, Real& a,
+                       Real& b) {
     /* one copy of the test per orientation: `type` is wave-uniform wherever the record came through
      * scalar loads, so this is a scalar branch, and no copy shuffles ray components through moves */
     /* (the empty asm statements differ, which keeps the optimiser from folding the copies back into one
      * body behind a chain of selects) */
     bool hit;
     if (type == RTR_NODE_XY_RECT) {
-        hit = rect_hit_axes<WAVE_EXIT>(n, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t, a, b);
+        hit = rect_hit_axes<WAVE_EXIT, SHARED>(n, o.z, d.z, q.rz, q, o.x, d.x, o.y, d.y, tmin, tmax, t, a, b);
         asm volatile("; xy_rect" : "+v"(t));
     } else if (type == RTR_NODE_XZ_RECT) {
-        hit = rect_hit_axes<WAVE_EXIT>(n, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t, a, b);
+        hit = rect_hit_axes<WAVE_EXIT, SHARED>(n, o.y, d.y, q.ry, q, o.x, d.x, o.z, d.z, tmin, tmax, t, a, b);
         asm volatile("; xz_rect" : "+v"(t));
     } else {
-        hit = rect_hit_axes<WAVE_EXIT>(n, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t, a, b);
+        hit = rect_hit_axes<WAVE_EXIT, SHARED>(n, o.x, d.x, q.rx, q, o.y, d.y, o.z, d.z, tmin, tmax, t, a, b);
         asm volatile("; yz_rect" : "+v"(t));
     }
     return hit;
@@ -390,20 +523,24 @@ RT_DEV void sphere_geom(const rtr_node& n, int type, Real time, V3& center, Real
         radius = n.f[8];
     }
 }
-RT_DEV bool sphere_hit_t(V3 center, Real radius, V3 o, V3 d, Real tmin, Real tmax, Real& t) {
+template <bool SHARED>
+RT_DEV bool sphere_hit_t(V3 center, Real radius, V3 o, V3 d, const RayDiv& q, Real tmin, Real tmax, Real& t) {
     V3 oc = sub(o, center);
-    Real a = len2(d);
+    Real a = SHARED ? q.a : len2(d); /* the same sum either way: |d|^2 of this frame, computed once */
     Real half_b = dot(oc, d);
     Real c = len2(oc) - radius * radius;
     Real discriminant = half_b * half_b - a * c;
     if (discriminant < 0) return false;
     Real sqrtd = __builtin_sqrt(discriminant);
-    t = (-half_b - sqrtd) / a;
+    t = div_shared<SHARED>(-half_b - sqrtd, a, q.ra, q.guard);
     if (t < tmin || t > tmax) {
-        t = (-half_b + sqrtd) / a;
+        t = div_shared<SHARED>(-half_b + sqrtd, a, q.ra, q.guard);
         if (t < tmin || t > tmax) return false;
     }
     return true;
+}
+RT_DEV bool sphere_hit_t(V3 center, Real radius, V3 o, V3 d, Real tmin, Real tmax, Real& t) {
+    return sphere_hit_t<false>(center, radius, o, d, raydiv_none(), tmin, tmax, t);
 }
 RT_DEV void sphere_fill(const rtr_node& n, int type, V3 center, Real radius, V3 o, V3 d, Real t, bool needs_uv,
                         Hit& rec) {
@@ -509,7 +646,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
             }
         } else if (type >= RTR_NODE_XY_RECT && type <= RTR_NODE_YZ_RECT) {
             Real t, a, b;
-            if (rect_hit_t(n, type, o, d, tmin, tmax, t, a, b)) {
+            if (rect_hit_t(n, type, o, d, raydiv_none(), tmin, tmax, t, a, b)) {
                 tmax = t;
                 ++hits;
                 if (FULL) rect_fill(n, type, o, d, t, a, b, sc.needs_uv != 0, rec);
@@ -623,8 +760,7 @@ struct BoxRay {
     float cfx, cfy, cfz;
     bool sx, sy, sz; /* direction negative: the box's max plane is the near one */
 };
-RT_DEV void boxray_axis(Real o, Real d, float bound, float& idir, float& cn, float& cf, bool& neg_dir) {
-    const Real inv = 1.0 / d;
+RT_DEV void boxray_axis(Real o, Real inv, float bound, float& idir, float& cn, float& cf, bool& neg_dir) {
     const Real ainv = __builtin_fabs(inv);
     const bool usable = ainv < 1e30; /* false for inf and NaN as well */
     const Real slack = 0x1p-21 * ainv * (__builtin_fabs(o) + (Real)bound);
@@ -634,13 +770,15 @@ RT_DEV void boxray_axis(Real o, Real d, float bound, float& idir, float& cn, flo
     cf = usable ? (float)(mid + slack) : __builtin_huge_valf();
     neg_dir = inv < 0;
 }
-RT_DEV BoxRay boxray_make(V3 o, V3 d, float bound) {
+/* `inv` = 1 / d up to a few ulps (the slack covers 2^-24 of it) */
+RT_DEV BoxRay boxray_make_inv(V3 o, V3 inv, float bound) {
     BoxRay r;
-    boxray_axis(o.x, d.x, bound, r.idx, r.cnx, r.cfx, r.sx);
-    boxray_axis(o.y, d.y, bound, r.idy, r.cny, r.cfy, r.sy);
-    boxray_axis(o.z, d.z, bound, r.idz, r.cnz, r.cfz, r.sz);
+    boxray_axis(o.x, inv.x, bound, r.idx, r.cnx, r.cfx, r.sx);
+    boxray_axis(o.y, inv.y, bound, r.idy, r.cny, r.cfy, r.sy);
+    boxray_axis(o.z, inv.z, bound, r.idz, r.cnz, r.cfz, r.sz);
     return r;
 }
+RT_DEV BoxRay boxray_make(V3 o, V3 d, float bound) { return boxray_make_inv(o, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z), bound); }
 /* round a double bound of the ray interval to float, outward */
 RT_DEV float float_below(Real t) {
     const float f = (float)t;
@@ -687,17 +825,17 @@ RT_DEV bool boxray_hit(const BoxRay& r, const float* bmin, const float* bmax, fl
  * coplanar side faces of adjacent boxes in scene 9, are won by whichever primitive is tested
  * last; in the reference that is decided by 1-ulp noise of its BVH box tests, so neither order
  * can be called "the" reference behaviour.  Such faces share material and normal there.) */
-template <bool WAVE_EXIT = false>
-RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t) {
+template <bool WAVE_EXIT = false, bool SHARED = false>
+RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, const RayDiv& q, Real time, Real tmin, Real tmax, Real& t) {
     const int type = n.type;
     if (type >= RTR_NODE_XY_RECT) {
         Real a, b;
-        return rect_hit_t<WAVE_EXIT>(n, type, o, d, tmin, tmax, t, a, b);
+        return rect_hit_t<WAVE_EXIT, SHARED>(n, type, o, d, q, tmin, tmax, t, a, b);
     }
     V3 center;
     Real radius;
     sphere_geom(n, type, time, center, radius);
-    return sphere_hit_t(center, radius, o, d, tmin, tmax, t);
+    return sphere_hit_t<SHARED>(center, radius, o, d, q, tmin, tmax, t);
 }
 /* Exact ties in t.  Every hit() of the reference accepts t == t_max, so of two surfaces at exactly the
  * same t the one its walk visits LATER wins (two coplanar rects with different materials).  Upload marks
@@ -712,10 +850,11 @@ RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, Real time, Real tmin, R
  * 1-ulp noise of an UNPADDED box test (faces of `box` objects that touch: the later one is only
  * visited if aabb::hit of its box, entered at exactly that t, survives `t_max <= t_min`). */
 #define RT_TIE_FLAG (1 << 30)
-template <bool TIES = true, bool WAVE_EXIT = false>
-RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t, int& order) {
+template <bool TIES = true, bool WAVE_EXIT = false, bool SHARED = false>
+RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, const RayDiv& q, Real time, Real tmin, Real tmax, Real& t,
+                         int& order) {
     const rtr_node n = ld_const(sc.fprim, ref);
-    if (!fast_prim_hit<WAVE_EXIT>(n, o, d, time, tmin, tmax, t)) return false;
+    if (!fast_prim_hit<WAVE_EXIT, SHARED>(n, o, d, q, time, tmin, tmax, t)) return false;
     const int tag = n.reserved;
     if (TIES && (tag & RT_TIE_FLAG)) {
         const int visit = tag & ~RT_TIE_FLAG;
@@ -725,11 +864,167 @@ RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real 
     return true;
 }
 
+template <bool TIES = true, bool WAVE_EXIT = false>
+RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, Real time, Real tmin, Real tmax, Real& t, int& order) {
+    return fast_ref_hit<TIES, WAVE_EXIT, false>(sc, ref, o, d, raydiv_none(), time, tmin, tmax, t, order);
+}
+
 /* Closest hit (ANY = false) or first hit found (ANY = true: shadow rays only need existence).
  * Returns the reference and instance of the hit; `tmax` returns its t.  TREES = false: the caller
  * knows that no instance of the scene has a box tree and no reference is tie-capable (RT_TRAV_FLAT),
  * which keeps that code and its registers out of the kernels of small scenes (the Cornell box:
  * 118 VGPRs, no spills). */
+/* ---- type runs of a linearly scanned instance (FInst::run) ------------------------------------------------------
+ * One rectangle of a run against the ray: the arithmetic of rect_hit_axes on a packed record. */
+template <int TYPE, bool WEXIT, bool SHARED>
+RT_DEV void run_rect_test(Real a0, Real a1, Real b0, Real b1, Real k, int ref, V3 o, V3 d, const RayDiv& q, Real tmin,
+                          Real& tmax, int& hit_ref) {
+    const Real ok = TYPE == RTR_NODE_XY_RECT ? o.z : (TYPE == RTR_NODE_XZ_RECT ? o.y : o.x);
+    const Real dk = TYPE == RTR_NODE_XY_RECT ? d.z : (TYPE == RTR_NODE_XZ_RECT ? d.y : d.x);
+    const Real rk = TYPE == RTR_NODE_XY_RECT ? q.rz : (TYPE == RTR_NODE_XZ_RECT ? q.ry : q.rx);
+    const Real oa = TYPE == RTR_NODE_YZ_RECT ? o.y : o.x, da = TYPE == RTR_NODE_YZ_RECT ? d.y : d.x;
+    const Real ob = TYPE == RTR_NODE_XY_RECT ? o.y : o.z, db = TYPE == RTR_NODE_XY_RECT ? d.y : d.z;
+    const Real t = div_shared<SHARED>(k - ok, dk, rk, q.guard);
+    const bool off = (t < tmin) | (t > tmax);
+    if (WEXIT && !__any(!off)) return;
+    const Real a = oa + t * da;
+    const Real b = ob + t * db;
+    const bool out = off | (a < a0) | (a > a1) | (b < b0) | (b > b1);
+    tmax = out ? tmax : t;
+    hit_ref = out ? hit_ref : ref;
+}
+template <int TYPE, bool WEXIT, bool SHARED>
+RT_DEV void run_rects(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
+                      int& hit_ref) {
+    int k = 0;
+    for (; k + 1 < cnt; k += 2, p += 10) { /* two records, one scalar-load round trip */
+        const Real f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3], f4 = p[4];
+        const Real g0 = p[5], g1 = p[6], g2 = p[7], g3 = p[8], g4 = p[9];
+        run_rect_test<TYPE, WEXIT, SHARED>(f0, f1, f2, f3, f4, ref + k, o, d, q, tmin, tmax, hit_ref);
+        run_rect_test<TYPE, WEXIT, SHARED>(g0, g1, g2, g3, g4, ref + k + 1, o, d, q, tmin, tmax, hit_ref);
+    }
+    if (k < cnt) run_rect_test<TYPE, WEXIT, SHARED>(p[0], p[1], p[2], p[3], p[4], ref + k, o, d, q, tmin, tmax, hit_ref);
+}
+template <bool SHARED>
+RT_DEV void run_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
+                        int& hit_ref) {
+    for (int k = 0; k < cnt; ++k, p += 4) {
+        Real t;
+        if (sphere_hit_t<SHARED>(mk(p[0], p[1], p[2]), p[3], o, d, q, tmin, tmax, t)) tmax = t, hit_ref = ref + k;
+    }
+}
+template <bool SHARED>
+RT_DEV void run_moving_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real time, Real tmin,
+                               Real& tmax, int& hit_ref) {
+    for (int k = 0; k < cnt; ++k, p += 9) {
+        const V3 c0 = mk(p[0], p[1], p[2]), c1 = mk(p[3], p[4], p[5]);
+        const V3 center = add(c0, scl((time - p[6]) / (p[7] - p[6]), sub(c1, c0))); /* moving_sphere.h:32-34 */
+        Real t;
+        if (sphere_hit_t<SHARED>(center, p[8], o, d, q, tmin, tmax, t)) tmax = t, hit_ref = ref + k;
+    }
+}
+/* every run of the instance, in visiting order (`t == t_max` is accepted: the later reference wins an exact tie) */
+template <bool WEXIT, bool SHARED>
+RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv& q, Real time, Real tmin, Real& tmax,
+                      int& hit_ref) {
+    const RT_CONST_AS double* p = as_const(sc.fscan) + I.scan_first;
+    int ref = I.ref_first;
+#pragma nounroll
+    for (uint64_t runs = I.runs; runs != 0; runs >>= 10) {
+        const int type = RTR_NODE_SPHERE + (int)((runs >> 7) & 7), cnt = (int)(runs & 127);
+        RT_REGION(type >= RTR_NODE_XY_RECT ? (WEXIT ? RG_SH_RECTS : RG_RECTS) : (WEXIT ? RG_SH_SPHERES : RG_SPHERES));
+        if (type == RTR_NODE_XY_RECT) {
+            run_rects<RTR_NODE_XY_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            p += 5 * cnt;
+        } else if (type == RTR_NODE_XZ_RECT) {
+            run_rects<RTR_NODE_XZ_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            p += 5 * cnt;
+        } else if (type == RTR_NODE_YZ_RECT) {
+            run_rects<RTR_NODE_YZ_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            p += 5 * cnt;
+        } else if (type == RTR_NODE_SPHERE) {
+            run_spheres<SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            p += 4 * cnt;
+        } else {
+            run_moving_spheres<SHARED>(p, cnt, ref, o, d, q, time, tmin, tmax, hit_ref);
+            p += 9 * cnt;
+        }
+        ref += cnt;
+    }
+}
+
+#ifndef RTR_TREE_SHARED
+#define RTR_TREE_SHARED 0 /* 1: kernels with box trees share reciprocals too (linear scans and leaf primitives) */
+#endif
+/* The references of one instance against the ray in the instance's frame: linear scan or box tree.  Returns true when
+ * an ANY cast has found its hit.  SHARED: see div_shared. */
+template <bool ANY, bool TREES, bool WEXIT, bool SHARED>
+__device__ __forceinline__ bool scan_instance(const DScene& sc, const FInst& I, V3 lo, V3 ld, const RayDiv& q, Real time,
+                                              Real tmin, Real& tmax, int& hit_ref, int& order, const Stack st, const int sp0) {
+    if (!TREES || I.bvh_root < 0) {
+        if (SHARED && (I.flags & RT_INST_RUNS)) {
+            /* (an ANY cast goes on after its first hit: a lane-level exit inside these loops costs every trip,
+             * and most shadow rays reach their light) */
+            scan_runs<WEXIT, SHARED>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
+            return ANY && hit_ref >= 0;
+        }
+        RT_REGION(WEXIT ? RG_SH_GENERIC : RG_GENERIC);
+        const int r0 = I.ref_first, r1 = r0 + I.n_ref;
+        for (int r = r0; r < r1; ++r) {
+            Real t;
+            if (fast_ref_hit<TREES, WEXIT, false>(sc, r, lo, ld, q, time, tmin, tmax, t, order)) {
+                tmax = t;
+                hit_ref = r;
+                if (ANY) return true;
+            }
+        }
+        return false;
+    }
+    /* while-while traversal: every lane first walks down to its next leaf, then the wave
+     * tests leaf primitives together (the expensive, exact part) */
+    const BoxRay br = boxray_make_inv(lo, SHARED ? mk(q.rx, q.ry, q.rz) : mk(1.0 / ld.x, 1.0 / ld.y, 1.0 / ld.z), I.bound);
+    const float tmin_f = float_below(tmin);
+    float tmax_f = float_above(tmax);
+    int sp = sp0;
+    int node = I.bvh_root;
+    while (true) {
+        RT_REGION(WEXIT ? RG_SH_TREE : RG_TREE);
+        while (node >= 0) {
+            const NodeRegs b = load_node(sc.fbvh, node);
+            float tl, tr;
+            const bool hl = boxray_hit(br, b.lmin, b.lmax, tmin_f, tmax_f, tl);
+            const bool hr = boxray_hit(br, b.rmin, b.rmax, tmin_f, tmax_f, tr);
+            const int cl = b.left, cr = b.right;
+            if (hl && hr) { /* nearer child first */
+                const bool left_first = tl <= tr;
+                st.put(sp++, left_first ? cr : cl);
+                node = left_first ? cl : cr;
+            } else if (hl) {
+                node = cl;
+            } else if (hr) {
+                node = cr;
+            } else {
+                node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
+            }
+        }
+        if (node == RT_BVH_DONE) break;
+        RT_REGION(WEXIT ? RG_SH_LEAVES : RG_LEAVES);
+        const int code = -1 - node;
+        const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
+        for (int r = r0; r < r1; ++r) {
+            Real t;
+            if (fast_ref_hit<TREES, WEXIT, SHARED && RTR_TREE_SHARED>(sc, r, lo, ld, q, time, tmin, tmax, t, order)) {
+                tmax = t;
+                tmax_f = float_above(t);
+                hit_ref = r;
+                if (ANY) return true;
+            }
+        }
+        node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
+    }
+    return false;
+}
+
 template <bool ANY, bool TREES, bool WEXIT>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
                                            Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
@@ -742,7 +1037,11 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
     hit_ref = -1;
     hit_inst = -1;
     int order = -1;
+#ifndef RTR_NO_SHARED_DIV
+    const bool origin_ok = (RTR_TREE_SHARED || !TREES) && sc.shared_div != 0 && raydiv_origin_ok(o);
+#endif
     for (int ii = inst_first; ii < inst_first + n_inst; ++ii) {
+        RT_REGION(WEXIT ? RG_SH_SETUP : RG_SETUP);
         const FInst I = ld_const(sc.finst, ii);
         V3 lo = o, ld = d;
         const int n_xf = I.n_xf;
@@ -751,73 +1050,43 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
                 Real tn;
                 if (!box_enter(I.bmin, I.bmax, o, inv, tmin, tmax, tn)) continue;
             }
-            for (int k = 0; k < n_xf; ++k) {
+            wrapper_enter(I.xf_type[0], I.xf_f[0], lo, ld);
+            if (n_xf > 1) wrapper_enter(I.xf_type[1], I.xf_f[1], lo, ld);
+            for (int k = RT_INST_XF_INLINE; k < n_xf; ++k) {
                 const FXf x = ld_const(sc.fxf, I.xf_first + k);
                 wrapper_enter(x.type, x.f, lo, ld);
             }
         }
-        if (!TREES || I.bvh_root < 0) {
-            const int r0 = I.ref_first, r1 = r0 + I.n_ref;
-            for (int r = r0; r < r1; ++r) {
-                Real t;
-                if (fast_ref_hit<TREES, WEXIT>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
-                    tmax = t;
-                    hit_ref = r;
-                    hit_inst = ii;
-                    if (ANY) return true;
-                }
-            }
-        } else {
-            /* while-while traversal: every lane first walks down to its next leaf, then the wave
-             * tests leaf primitives together (the expensive, exact part) */
-            const BoxRay br = boxray_make(lo, ld, I.bound);
-            const float tmin_f = float_below(tmin);
-            float tmax_f = float_above(tmax);
-            int sp = sp0;
-            int node = I.bvh_root;
-            while (true) {
-                while (node >= 0) {
-                    const NodeRegs b = load_node(sc.fbvh, node);
-                    float tl, tr;
-                    const bool hl = boxray_hit(br, b.lmin, b.lmax, tmin_f, tmax_f, tl);
-                    const bool hr = boxray_hit(br, b.rmin, b.rmax, tmin_f, tmax_f, tr);
-                    const int cl = b.left, cr = b.right;
-                    if (hl && hr) { /* nearer child first */
-                        const bool left_first = tl <= tr;
-                        st.put(sp++, left_first ? cr : cl);
-                        node = left_first ? cl : cr;
-                    } else if (hl) {
-                        node = cl;
-                    } else if (hr) {
-                        node = cr;
-                    } else {
-                        node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
-                    }
-                }
-                if (node == RT_BVH_DONE) break;
-                const int code = -1 - node;
-                const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
-                for (int r = r0; r < r1; ++r) {
-                    Real t;
-                    if (fast_ref_hit<TREES, WEXIT>(sc, r, lo, ld, time, tmin, tmax, t, order)) {
-                        tmax = t;
-                        tmax_f = float_above(t);
-                        hit_ref = r;
-                        hit_inst = ii;
-                        if (ANY) return true;
-                    }
-                }
-                node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
-            }
+        /* what the divisions of this frame share (see div_shared); made per frame rather than carried from the world
+         * frame: fifteen instructions against six registers held across the instance loop */
+        /* (kernels with box trees are bound by registers and the latency of their node fetches, not by instruction
+         * count: the shared reciprocals cost them more in spills than the shorter divisions return -- measured on
+         * scenes 9 / 22: 1 500 -> 1 350 and 770 -> 630 Msamples/s -- so they keep the plain divisions) */
+        RayDiv q = raydiv_none();
+#ifndef RTR_NO_SHARED_DIV /* experiments: the plain divisions, none of the shared-reciprocal code */
+        if (RTR_TREE_SHARED || !TREES) {
+            q = raydiv_make(ld, tmin, origin_ok);
+            if (I.flags & RT_INST_SPHERES) raydiv_spheres(q, ld);
         }
+#endif
+        /* references are numbered instance by instance: a hit of this instance is one with ref >= ref_first */
+        bool found;
+        if (q.fast)
+            found = scan_instance<ANY, TREES, WEXIT, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref, order, st, sp0);
+        else
+            found = scan_instance<ANY, TREES, WEXIT, false>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref, order, st, sp0);
+        RT_REGION(WEXIT ? RG_SH_SETUP : RG_SETUP);
+        if (hit_ref >= I.ref_first) hit_inst = ii;
+        if (ANY && found) return true;
     }
     return hit_ref >= 0;
 }
 
 /* Build the reference's hit_record for (reference, instance, t): the primitive's own hit()
- * tail in the instance frame, then the epilogues of the wrappers above it, innermost first. */
+ * tail in the instance frame, then the epilogues of the wrappers above it, innermost first.  Generic form:
+ * any chain length, wrapper list through FRef / fexit / nodes (one dependent load per hop). */
 template <bool UV>
-RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec) {
+__device__ __forceinline__ void fast_finish_long(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec) {
     const FInst I = ld_const(sc.finst, inst);
     const FRef R = ld_const(sc.fref, ref);
     V3 lo = o, ld = d;
@@ -860,6 +1129,71 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
         wrapper_epilogue(w, wd, rec);
     }
 }
+/* translate::hit / rotate_y::hit / flip_face::hit after the child hit, from a transform op instead of a node record
+ * (hittable.h:58-61,142-155,168: the arithmetic of wrapper_epilogue) */
+RT_DEV void xf_epilogue(int type, const double* f, V3 wd, Hit& rec) {
+    if (type == RTR_NODE_TRANSLATE) {
+        rec.p = add(rec.p, ld3(f));
+        set_face_normal(rec, wd, rec.n);
+    } else {
+        const Real s = f[0], c = f[1];
+        V3 p = rec.p, nn = rec.n;
+        p.x = c * rec.p.x + s * rec.p.z;
+        p.z = -s * rec.p.x + c * rec.p.z;
+        nn.x = c * rec.n.x + s * rec.n.z;
+        nn.z = -s * rec.n.x + c * rec.n.z;
+        rec.p = p;
+        set_face_normal(rec, wd, nn);
+    }
+}
+/* The usual case -- a chain of at most two transforms -- needs the instance record (ops inline) and the primitive
+ * record (geometry + wrapper code in f[9]): two independent loads, one round trip, where the generic form chases
+ * FInst -> FXf, FRef -> fexit -> nodes per wrapper. */
+template <bool UV>
+RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec) {
+    RT_REGION(RG_FINISH);
+    const FInst I = ld_const(sc.finst, inst);
+    const rtr_node n = ld_const(sc.fprim, ref);
+    unsigned long long code = (unsigned long long)__double_as_longlong(n.f[9]);
+    const int type = n.type;
+    if (I.n_xf > RT_INST_XF_INLINE || type == RTR_NODE_MOVING_SPHERE || code == RT_EXIT_LONG) {
+        fast_finish_long<UV>(sc, o, d, time, t, ref, inst, rec);
+        return;
+    }
+    /* the ray as each wrapper passed it down: after op 0, after op 1 (only directions matter to the epilogues) */
+    V3 lo = o, ld = d;
+    V3 d1 = d;
+    if (I.n_xf > 0) {
+        wrapper_enter(I.xf_type[0], I.xf_f[0], lo, ld);
+        d1 = ld;
+        if (I.n_xf > 1) wrapper_enter(I.xf_type[1], I.xf_f[1], lo, ld);
+    }
+    if (type >= RTR_NODE_XY_RECT) {
+        Real oa, da, ob, db;
+        if (type == RTR_NODE_XY_RECT) {
+            oa = lo.x, da = ld.x, ob = lo.y, db = ld.y;
+        } else if (type == RTR_NODE_XZ_RECT) {
+            oa = lo.x, da = ld.x, ob = lo.z, db = ld.z;
+        } else {
+            oa = lo.y, da = ld.y, ob = lo.z, db = ld.z;
+        }
+        rect_fill(n, type, lo, ld, t, oa + t * da, ob + t * db, UV, rec);
+    } else {
+        sphere_fill(n, type, ld3(n.f), n.f[3], lo, ld, t, UV, rec);
+    }
+    int level = I.n_xf;
+    for (; code != 0; code >>= 2) {
+        if ((code & 3) == 2) {
+            rec.front = !rec.front;
+        } else {
+            --level; /* 1 or 0: selected by hand, an indexed access would put the record into scratch memory */
+            const bool outer = level == 0;
+            const double f[3] = {outer ? I.xf_f[0][0] : I.xf_f[1][0], outer ? I.xf_f[0][1] : I.xf_f[1][1],
+                                 outer ? I.xf_f[0][2] : I.xf_f[1][2]};
+            xf_epilogue(outer ? I.xf_type[0] : I.xf_type[1], f, outer ? d1 : ld, rec);
+        }
+    }
+}
 
 /* ---- the two ray casts of the integrators, for either traversal ------------------------------ */
 /* TRAV: 0 = reference-order traversal, 1 = the same with constant_medium support, 2 = compiled scene */
@@ -879,9 +1213,11 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
     ref = -1, inst = -1, med = -1;
     bool any = false;
     const int n_steps = sc.n_fstep;
+
     for (int k = 0; k < n_steps; ++k) {
         /* a shadow ray that is blocked may stop once no medium is left to draw */
         if (ANY && any && k >= sc.fstep_tail) break;
+        RT_REGION(RG_MEDIA);
         const FStep step = ld_const(sc.fstep, k);
         /* constant_medium.h:68-103 once both boundary hits exist: clip to the ray's interval, draw, scatter or not */
         auto medium_between = [&](Real t1, Real t2) {
@@ -907,9 +1243,23 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
             const V3 center = ld3(n.f);
             const Real radius = n.f[3];
             Real t1, t2;
-            if (sphere_hit_t(center, radius, o, d, -RT_INF, RT_INF, t1) &&
-                sphere_hit_t(center, radius, o, d, t1 + 0.0001, RT_INF, t2))
+            /* both boundary casts divide by |d|^2 of the world frame, up to four times (t_min = -inf here: tiny
+             * numerators take the plain division) */
+            RayDiv mq = raydiv_none();
+            if (RTR_TREE_SHARED && sc.shared_div) {
+                mq.guard = true;
+                mq.a = len2(d);
+                mq.ra = rcp_refined(mq.a);
+                mq.fast = raydiv_origin_ok(o) && __all(rcp_safe(mq.a));
+            }
+            if (mq.fast) {
+                if (sphere_hit_t<true>(center, radius, o, d, mq, -RT_INF, RT_INF, t1) &&
+                    sphere_hit_t<true>(center, radius, o, d, mq, t1 + 0.0001, RT_INF, t2))
+                    medium_between(t1, t2);
+            } else if (sphere_hit_t(center, radius, o, d, -RT_INF, RT_INF, t1) &&
+                       sphere_hit_t(center, radius, o, d, t1 + 0.0001, RT_INF, t2)) {
                 medium_between(t1, t2);
+            }
             continue;
         }
         const FSub sub = ld_const(sc.fsub, step.sub);
@@ -1199,6 +1549,7 @@ RT_DEV Real reflectance(Real cosine, Real ref_idx) { /* material.h:199-203 */
 
 template <int MS = RT_MS_FULL>
 RT_DEV MatCtx mat_prepare(const DScene& sc, const Hit& rec) {
+    RT_REGION(RG_MATPREP);
     const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
     MatCtx c;
     c.type = m.type;
@@ -1692,6 +2043,7 @@ struct ShadowReq {
 template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS>
 RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, const MatCtx& mc, V3 wo, uint32_t& rng,
                         ShadowReq& rq) {
+    RT_REGION(RG_SHADE_A);
     const bool have_lights = sc.n_lights > 0;
     rq.valid = false;
     if (INTEG == RTR_INTEGRATOR_PBR) {
@@ -1760,6 +2112,7 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, const M
 template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS>
 RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, const MatCtx& mc, V3 wo, uint32_t& rng,
                         int rr_start) {
+    RT_REGION(RG_SHADE_B);
     BSDFSample bs;
     if (!mat_sample<MS>(mc, rec, wo, bs, rng)) { /* :106-118 */
         if (INTEG != RTR_INTEGRATOR_MIS) return false; /* pbr_path_integrator.h:44-46, direct_light_integrator.h:67-69 */
@@ -1793,6 +2146,7 @@ RT_DEV bool shade_b_mis(const DScene& sc, PathState& ps, const Hit& rec, const M
 template <int MS = RT_MS_FULL>
 RT_DEV bool shade_rr(const DScene& sc, PathState& ps, const Hit& rec, uint32_t& rng, int rr_start) {
     const MatCtx mc = mat_prepare<MS>(sc, rec);
+    RT_REGION(RG_SHADE_RR);
     ps.L = add(ps.L, mul(ps.thr, mat_emitted_legacy(mc)));
     V3 attenuation, ndir;
     if (!mat_scatter<MS>(mc, ps.rd, rec, attenuation, ndir, rng)) return false;

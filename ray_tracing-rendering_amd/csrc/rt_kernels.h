@@ -67,6 +67,12 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
     const DScene& sc = *scp;
     const Stack st{lds_stack + threadIdx.x};
     const Park pk{reinterpret_cast<double*>(lds_stack + stack_words * RTR_BLOCK) + threadIdx.x};
+#ifdef RTR_REGION_PROFILE
+    if (threadIdx.x < 4 * 2 * RT_PROF_REGIONS + 8) rt_prof_lds[threadIdx.x] = 0;
+    if (threadIdx.x + 256 < 4 * 2 * RT_PROF_REGIONS + 8) rt_prof_lds[threadIdx.x + 256] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) rt_prof_lds[4 * 2 * RT_PROF_REGIONS + (threadIdx.x >> 6) * 2] = __builtin_readcyclecounter();
+#endif
     int slot, chunk;
     mega_work(P, blockIdx.x, slot, chunk);
     const int cell = slot * P.chunks + chunk; /* partial sum / completion word of this (tile, chunk) */
@@ -141,6 +147,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
         while (!done) {
             bool pending = false, ended = false;
             RTR_CLK(clk_other);
+            RT_REGION(RG_OTHER);
             {
                 Hit rec;
                 rec.u = 0, rec.v = 0;
@@ -148,6 +155,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                 const bool hit_any = cast_closest<TRAV, MS == RT_MS_FULL>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st);
                 RTR_CLK(clk_closest);
                 if (!hit_any) {
+                    RT_REGION(RG_MISS);
                     pk.set3(PK_L, add(pk.get3(PK_L), miss_radiance<INTEG, MS>(sc, pk.get3(PK_THR), ps.ro, ps.rd, ps.depth,
                                                                           ps.specular_bounce, pk.get(PK_PDF))));
                     ended = true;
@@ -189,6 +197,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                         }
                         go = shade_b_mis<MS, INTEG>(sc, ps, rec, mc, wo, rng, P.rr_start);
                     }
+                    RT_REGION(RG_PARK);
                     ps.ro = rec.p; /* next ray origin and shadow ray origin */
                     pk.set3(PK_THR, ps.thr);
                     if (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0) pk.set3(PK_L, add(pk.get3(PK_L), ps.L));
@@ -197,12 +206,14 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                 }
             }
             RTR_CLK(clk_shade);
+            RT_REGION(RG_OTHER);
             if (pending) { /* mis_path_integrator.h:210-213, origin = the hit point = ps.ro */
                 pk.set(PK_NSHADOW, pk.get(PK_NSHADOW) + 1.0);
                 if (!cast_shadow<TRAV>(sc, ps.ro, pk.get3(PK_SWI), pk.get(PK_STMAX), rng, st))
                     pk.set3(PK_L, add(pk.get3(PK_L), pk.get3(PK_CONTRIB)));
             }
             RTR_CLK(clk_shadow);
+            RT_REGION(RG_REGEN);
             if (ended) {
                 pk.set3(PK_ACC, add(pk.get3(PK_ACC), pk.get3(PK_L))); /* renderer.h:77-78 */
                 ++n_samples;
@@ -224,6 +235,15 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
         }
 #endif
     }
+#ifdef RTR_REGION_PROFILE
+    RT_REGION(RG_OTHER);
+    __syncthreads();
+    if (threadIdx.x < 2 * RT_PROF_REGIONS) {
+        unsigned long long v = 0;
+        for (int w = 0; w < 4; ++w) v += rt_prof_lds[w * 2 * RT_PROF_REGIONS + threadIdx.x];
+        if (v) atomicAdd(&P.stats[RT_PROF_BASE + threadIdx.x], v);
+    }
+#endif
     const V3 acc = pk.get3(PK_ACC);
     double* out = P.partial + (size_t)cell * 3 * RTR_BLOCK + threadIdx.x;
     out[0] = acc.x;
@@ -384,6 +404,48 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_sincos(unsigned long long* m
         sincos(phi, &s2, &c2);
         const Real s1 = sin(phi), c1 = cos(phi);
         bad += (__double_as_longlong(s1) != __double_as_longlong(s2)) | (__double_as_longlong(c1) != __double_as_longlong(c2));
+    }
+    bad = wave_sum(bad);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
+/* rtr_test_shared_division: div_shared() against the compiler's n / d on 2^32 operand pairs.  Three quarters of them
+ * take both operands from the whole range the short form is used in (|d| in [2^-100, 2^100), |n| in [2^-300, 2^200),
+ * random mantissas and signs); the rest are shaped like the rectangle test's (k - o) / d: a difference of two
+ * coordinates below 1000 over a direction component in (-1, 1), small values of both included.  Quotients of
+ * numerators below 2^-300 are only required to stay below 2^-200 (see div_shared). */
+__global__ void __launch_bounds__(RTR_BLOCK) k_test_shared_div(unsigned long long* mismatches, unsigned per_thread) {
+    unsigned long long x = 0x9E3779B97F4A7C15ull * ((unsigned long long)blockIdx.x * RTR_BLOCK + threadIdx.x + 1);
+    auto next = [&]() {
+        x ^= x >> 12, x ^= x << 25, x ^= x >> 27;
+        return x * 0x2545F4914F6CDD1Dull;
+    };
+    auto make = [&](int emin, int espan) { /* +-1.m * 2^e, e in [emin, emin + espan) */
+        const unsigned long long u = next();
+        const int e = emin + (int)((u >> 52) % (unsigned)espan);
+        const double m = __longlong_as_double((u & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+        return ldexp(m, e);
+    };
+    unsigned long long bad = 0;
+    for (unsigned k = 0; k < per_thread; ++k) {
+        double n, d;
+        if (k & 3) {
+            d = make(-100, 200), n = make(-300, 500);
+        } else {
+            const double o = (double)(long long)(next() >> 11) * 0x1p-53 * 2000.0 - 1000.0;
+            const double p = (k & 4) ? o + make(-60, 60) : (double)(long long)(next() >> 11) * 0x1p-53 * 2000.0 - 1000.0;
+            n = p - o;
+            d = (k & 8) ? make(-40, 40) : (double)(long long)(next() >> 11) * 0x1p-52 - 1.0;
+        }
+        if (!rcp_safe(d)) continue;
+        const double r = rcp_refined(d);
+        const double t = div_shared<true>(n, d, r, false), ref = n / d;
+        if (__builtin_fabs(n) >= 0x1p-300)
+            bad += __double_as_longlong(t) != __double_as_longlong(ref);
+        else
+            bad += !(__builtin_fabs(t) < 0x1p-200) || !(__builtin_fabs(ref) < 0x1p-200);
+        const double g = div_shared<true>(n, d, r, true); /* guarded: every numerator */
+        bad += __double_as_longlong(g) != __double_as_longlong(ref);
     }
     bad = wave_sum(bad);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);

@@ -41,7 +41,7 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan;
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool force_exact = false;
@@ -495,8 +495,25 @@ int finish_stats(rtr_context* c) {
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    unsigned long long h[8] = {0};
+    unsigned long long h[RT_STATS_WORDS] = {0};
     HIPCHK(c, hipMemcpy(h, c->b_stats.p, sizeof h, hipMemcpyDeviceToHost));
+    if (getenv("RTR_REGION_PROFILE")) { /* a -DRTR_REGION_PROFILE build filled these (rt_device.h: RT_REGION) */
+        static const char* names[RG_N] = {"other / loop", "closest: instance setup", "closest: rect runs", "closest: sphere runs",
+                                          "closest: generic scan", "closest: tree inner nodes", "closest: tree leaves",
+                                          "closest: hit record (fast_finish)", "shadow: instance setup", "shadow: rect runs",
+                                          "shadow: sphere runs", "shadow: generic scan", "shadow: tree inner nodes",
+                                          "shadow: tree leaves", "media steps", "mat_prepare", "shade_a (emission, light sample)",
+                                          "shade_b (BSDF sample, roulette)", "miss", "end of sample + regeneration",
+                                          "shade_rr / shade_path", "park path state"};
+        double total = 0;
+        for (int k = 0; k < RG_N; ++k) total += (double)h[RT_PROF_BASE + k];
+        std::fprintf(stderr, "[region profile] %.4g wave cycles in all, %llu samples\n", total, h[0]);
+        for (int k = 0; k < RG_N; ++k)
+            if (h[RT_PROF_BASE + RT_PROF_REGIONS + k])
+                std::fprintf(stderr, "[region profile] %-36s %6.2f %%  %12llu visits  %8.1f cycles/visit\n", names[k],
+                             100.0 * (double)h[RT_PROF_BASE + k] / total, h[RT_PROF_BASE + RT_PROF_REGIONS + k],
+                             (double)h[RT_PROF_BASE + k] / (double)h[RT_PROF_BASE + RT_PROF_REGIONS + k]);
+    }
 #ifdef RTR_PHASE_CLOCKS
     std::fprintf(stderr, "[phase clocks] closest %.3e  shade %.3e  shadow %.3e  other %.3e (wave cycles)\n", (double)h[3],
                  (double)h[4], (double)h[5], (double)h[6]);
@@ -582,7 +599,7 @@ int rtr_create(int device_ordinal, rtr_context** out_ctx) {
     CREATE_CHK(hipEventCreate(&c->ev1));
 #undef CREATE_CHK
     c->stream = c->own_stream;
-    int rc = ensure(c, c->b_stats, 8 * sizeof(unsigned long long));
+    int rc = ensure(c, c->b_stats, RT_STATS_WORDS * sizeof(unsigned long long));
     if (!rc) rc = ensure(c, c->b_cancel, sizeof(uint32_t));
     if (!rc && hipMemset(c->b_cancel.p, 0, sizeof(uint32_t)) != hipSuccess) rc = RTR_ERR_DEVICE;
     if (rc) {
@@ -600,7 +617,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_done, &c->b_stats, &c->b_cancel, &c->b_test, &c->b_stage,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit, &c->b_fscan};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -643,7 +660,6 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     info.fast_refs = (int32_t)cs.ref.size();
     info.fast_stack_words = cs.stack_words;
     info.compiled_subtrees = cs.n_compiled_subtrees;
-    if ((rc = upload(c, c->b_finst, cs.inst.data(), sizeof(FInst) * cs.inst.size()))) return rc;
     if ((rc = upload(c, c->b_fxf, cs.xf.data(), sizeof(FXf) * cs.xf.size()))) return rc;
     if ((rc = upload(c, c->b_fref, cs.ref.data(), sizeof(FRef) * cs.ref.size()))) return rc;
     if ((rc = upload(c, c->b_fexit, cs.exits.data(), sizeof(int32_t) * cs.exits.size()))) return rc;
@@ -685,6 +701,15 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
         for (size_t k = 0; k < cs.ref.size(); ++k) {
             prims[k] = s->nodes[cs.ref[k].node]; /* original records */
             prims[k].reserved = cs.ref[k].pad;      /* visiting order of the reference's walk */
+            /* the wrappers above the reference as a code in f[9] (see RT_EXIT_LONG) */
+            unsigned long long code = 0;
+            bool fits = prims[k].type != RTR_NODE_MOVING_SPHERE && cs.ref[k].n_exit <= 31;
+            for (int e = 0; e < cs.ref[k].n_exit && fits; ++e) {
+                const int wt = s->nodes[cs.exits[cs.ref[k].exit_first + e]].type;
+                code |= (unsigned long long)(wt == RTR_NODE_FLIP_FACE ? 2 : 1) << (2 * e);
+            }
+            if (!fits) code = RT_EXIT_LONG;
+            if (prims[k].type != RTR_NODE_MOVING_SPHERE) std::memcpy(&prims[k].f[9], &code, 8);
         }
         /* references that can tie exactly in t with another one of their instance (see RT_TIE_FLAG) */
         for (const FInst& I : cs.inst) {
@@ -783,6 +808,9 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
             }
         }
         if ((rc = upload(c, c->b_fprim, prims.data(), sizeof(rtr_node) * prims.size()))) return rc;
+        rtc::build_scan_runs(cs, prims);
+        if ((rc = upload(c, c->b_fscan, cs.scan.data(), sizeof(double) * cs.scan.size()))) return rc;
+        if ((rc = upload(c, c->b_finst, cs.inst.data(), sizeof(FInst) * cs.inst.size()))) return rc;
     }
     c->fast_stack_words = cs.stack_words;
     c->flat_scene = cs.ok && cs.bvh.empty() && !any_tie;
@@ -792,6 +820,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fxf = static_cast<const FXf*>(c->b_fxf.p);
     d.fref = static_cast<const FRef*>(c->b_fref.p);
     d.fprim = static_cast<const rtr_node*>(c->b_fprim.p);
+    d.fscan = static_cast<const double*>(c->b_fscan.p);
     d.fexit = static_cast<const int32_t*>(c->b_fexit.p);
     d.fbvh = static_cast<const FBvh*>(c->b_fbvh.p);
     d.fsub = static_cast<const FSub*>(c->b_fsub.p);
@@ -815,6 +844,21 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.n_nodes = s->n_nodes;
     d.n_lights = s->n_lights;
     d.needs_uv = info.needs_uv;
+    /* div_shared's range argument: numerators are differences of scene coordinates and ray origins */
+    d.shared_div = 1;
+    for (int k = 0; k < s->n_nodes && d.shared_div; ++k) {
+        const rtr_node& n = s->nodes[k];
+        const int nf = n.type == RTR_NODE_TRANSLATE ? 3 : n.type == RTR_NODE_SPHERE ? 4 : n.type == RTR_NODE_MOVING_SPHERE ? 9
+                       : n.type >= RTR_NODE_XY_RECT ? 5 : 0;
+        for (int q = 0; q < nf; ++q)
+            if (!(std::fabs(n.f[q]) <= 0x1p60)) d.shared_div = 0;
+        /* moving_sphere::center(time) scales (c1 - c0) by (time - t0) / (t1 - t0) */
+        if (n.type == RTR_NODE_MOVING_SPHERE && !(std::fabs(n.f[7] - n.f[6]) >= 0x1p-20)) d.shared_div = 0;
+    }
+    if (!(std::fabs(s->camera.time0) <= 0x1p60 && std::fabs(s->camera.time1) <= 0x1p60)) d.shared_div = 0;
+    for (const FInst& I : cs.inst)
+        if (I.n_xf > 30) d.shared_div = 0;
+    if (getenv("RTR_NO_SHARED_DIV")) d.shared_div = 0; /* experiments: the plain divisions */
     c->info = info;
     c->n_materials = s->n_materials;
     c->lean_materials = true;
@@ -920,7 +964,7 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     c->stats = rtr_render_stats{};
     c->stats.spp_chunks = chunks;
     c->pending_id = id;
-    HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->b_stats.p, 0, RT_STATS_WORDS * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pipeline == RTR_PIPELINE_WAVEFRONT) {
         int launches = 0;
@@ -1170,6 +1214,24 @@ int rtr_test_sincos_exhaustive(rtr_context* c, uint64_t* mismatches) {
     HIPCHK(c, hipMemsetAsync(c->b_test.p, 0, 8, c->stream));
     hipLaunchKernelGGL(k_test_sincos, dim3((unsigned)(c->n_cus * 16)), dim3(RTR_BLOCK), 0, c->stream,
                        static_cast<unsigned long long*>(c->b_test.p));
+    HIPCHK(c, hipGetLastError());
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, c->b_test.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *mismatches = h;
+    return RTR_OK;
+}
+
+int rtr_test_shared_division(rtr_context* c, uint64_t* mismatches) {
+    if (!c || !mismatches) return RTR_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = ensure(c, c->b_test, 8);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->b_test.p, 0, 8, c->stream));
+    const unsigned blocks = 4096, per_thread = (unsigned)((1ull << 32) / ((unsigned long long)blocks * RTR_BLOCK));
+    hipLaunchKernelGGL(k_test_shared_div, dim3(blocks), dim3(RTR_BLOCK), 0, c->stream,
+                       static_cast<unsigned long long*>(c->b_test.p), per_thread);
     HIPCHK(c, hipGetLastError());
     unsigned long long h = 0;
     HIPCHK(c, hipMemcpyAsync(&h, c->b_test.p, 8, hipMemcpyDeviceToHost, c->stream));

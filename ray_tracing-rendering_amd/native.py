@@ -22,7 +22,7 @@ EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "
            "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_synchronize", "rtr_cancel",
            "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
            "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order", "rtr_test_stream8",
-           "rtr_test_sincos_exhaustive")
+           "rtr_test_sincos_exhaustive", "rtr_test_shared_division")
 
 
 class SceneInfoC(C.Structure):
@@ -81,6 +81,8 @@ def lib():
     L.rtr_test_reference_order.argtypes = [vp, C.c_int]
     L.rtr_test_stream8.argtypes = [vp, C.c_int64, C.c_int]
     L.rtr_test_sincos_exhaustive.argtypes = [vp, C.POINTER(C.c_uint64)]
+    if hasattr(L, "rtr_test_shared_division"):  # absent from older builds used through RTR_HIP_LIBRARY
+        L.rtr_test_shared_division.argtypes = [vp, C.POINTER(C.c_uint64)]
     if L.rtr_abi_version() != A.RTR_ABI_VERSION:
         raise RtrError(A.RTR_ERR_INVALID, "librtr_hip.so ABI version mismatch")
     _LIB = L
@@ -205,6 +207,12 @@ class Context:
         """All 2^32 sampler angles: how many give sincos(phi) != (sin(phi), cos(phi)) in some bit (include/rtr_hip_test.h)."""
         n = C.c_uint64(0)
         self._chk(self._L.rtr_test_sincos_exhaustive(self._h, C.byref(n)))
+        return int(n.value)
+
+    def shared_division_mismatches(self):
+        """2^32 operand pairs: how many quotients of the shared-reciprocal division differ from n / d (include/rtr_hip_test.h)."""
+        n = C.c_uint64(0)
+        self._chk(self._L.rtr_test_shared_division(self._h, C.byref(n)))
         return int(n.value)
 
     # device unit kernels over golden-vector records (include/rtr_hip_test.h)
