@@ -55,6 +55,12 @@ int rtr_test_stream8(rtr_context* ctx, int64_t n_doubles, int repeat);
  * s and counts those where sincos(phi) and the pair sin(phi), cos(phi) differ in any bit: *mismatches must be 0. */
 int rtr_test_sincos_exhaustive(rtr_context* ctx, uint64_t* mismatches);
 
+/* Measured issue costs for bench.py's `valu_slot_utilisation`: shader cycles a wave spends per instruction of one class
+ * while four waves share each SIMD (so a pipe-bound class reads four times its pipe cost), classes in this order:
+ * v_fma_f64, v_add_f64, v_mul_f64, v_rcp_f64, v_rsq_f64, v_cmp_lt_f64, v_cndmask_b32, v_mov_b32, v_fma_f32, s_and_b64,
+ * v_div_scale_f64, v_div_fixup_f64, {v_cmp_lt_f64 + dependent s_and_b64}.  Fills cycles_per_inst[0 .. n) (n <= 13). */
+int rtr_test_issue_rates(rtr_context* ctx, double* cycles_per_inst, int n);
+
 /* The primitive tests divide many numerators by the same ray-direction component through a shared refined reciprocal
  * (rt_device.h: div_shared) instead of the compiler's eleven-instruction division.  This compares the two on 2^32
  * operand pairs from the range the short form is used in; *mismatches (quotients that differ in any bit) must be 0. */

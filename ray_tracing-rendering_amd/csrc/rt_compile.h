@@ -40,6 +40,8 @@ namespace rtc {
  * flags (rtr_upload_scene).  Instances whose references do not fit RT_INST_RUNS_MAX runs, or that hold a tie-capable
  * reference (its visiting position takes part in the test), keep the generic loop. */
 inline void build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>& prims);
+/* FLeaf record of every reference */
+inline std::vector<FLeaf> build_leaf_records(const CompiledScene& cs, const std::vector<rtr_node>& prims);
 
 constexpr int kLinearMax = 12; /* instances with more references get a box tree */
 constexpr int kLeafMax = 4;
@@ -635,4 +637,17 @@ inline void rtc::build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>&
         I.flags |= RT_INST_RUNS;
     }
     cs.scan.resize(cs.scan.size() + 16, 0.0); /* the two-records-per-trip loads never leave the array */
+}
+
+inline std::vector<FLeaf> rtc::build_leaf_records(const CompiledScene& cs, const std::vector<rtr_node>& prims) {
+    std::vector<FLeaf> out(prims.size());
+    for (size_t r = 0; r < prims.size(); ++r) {
+        FLeaf L{};
+        const rtr_node& n = prims[r];
+        const int nf = n.type == RTR_NODE_SPHERE ? 4 : (n.type == RTR_NODE_MOVING_SPHERE ? 0 : 5);
+        for (int k = 0; k < nf; ++k) L.f[k] = n.f[k];
+        L.type = n.type, L.tag = n.reserved;
+        out[r] = L;
+    }
+    return out;
 }

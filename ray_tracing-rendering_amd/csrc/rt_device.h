@@ -282,6 +282,7 @@ struct DScene {
     const struct FRef* fref;
     const rtr_node* fprim; /* copy of the primitive's node record per reference (one load hop less) */
     const double* fscan;   /* packed geometry of linearly scanned references (see FInst) */
+    const struct FLeaf* fleaf; /* leaf records of the box trees, one per reference (see FLeaf) */
     const int32_t* fexit;
     const struct FBvh* fbvh;
     const struct FSub* fsub; /* compiled sub-scenes: [0] = whole scene when it has no media */
@@ -358,6 +359,17 @@ struct FBvh {
     int32_t pad[2];
 };
 #define RT_BVH_DONE (-2147483647 - 1) /* traversal sentinel: nothing left on the stack */
+/* What a lane fetches per reference of a tree leaf: 64 bytes instead of the 96-byte node record.  (A leaf holding the six
+ * sides of a `box` as ONE record -- one fetch, three shared reciprocals, the six rectangle tests in list order -- was built
+ * and measured: half the leaf instructions, bit-identical, and 3 % SLOWER on scenes 9 / 22 (1 459 vs 1 510 Msamples/s): the
+ * tree kernels are bound by the latency of dependent fetches at three waves per SIMD and by their spills, not by
+ * instruction count; profiles/README.md.) */
+struct FLeaf {
+    double f[6];  /* x?_rect: a0 a1 b0 b1 k; sphere: centre radius */
+    int32_t type; /* RTR_NODE_*; a moving_sphere is tested from its fprim record */
+    int32_t tag;  /* fprim[].reserved: tie flag | visiting position */
+    int32_t pad[2];
+};
 /* A compiled sub-scene = a range of instances.  Scenes WITH media keep the reference-order walk
  * for the (small) part of the graph the media live in, and every large media-free subtree under
  * it is compiled on its own: the walk meets it as one node of type RT_NODE_COMPILED at the place
@@ -893,6 +905,74 @@ RT_DEV void run_rect_test(Real a0, Real a1, Real b0, Real b1, Real k, int ref, V
     tmax = out ? tmax : t;
     hit_ref = out ? hit_ref : ref;
 }
+/* The same test for SHARED frames as one hand-scheduled block.  Every instruction of these loops costs a wave the same
+ * issue slot, scalar or vector (tools/issue_rates.py: v_fma_f64 2.8, v_cmp_f64 2.8, s_and_b64 2.8 cycles per SIMD), and the
+ * compiler's form spends eleven of its twenty-four on the acceptance mask and the conditional update: six compares into
+ * scalar pairs, five scalar ORs, a move and three selects.  Here each compare narrows EXEC itself (v_cmpx), the update is
+ * two moves executed by the lanes that are left, and EXEC is put back: eighteen instructions, the same arithmetic on the
+ * same operands in the same order (a SHARED frame produces no NaN, so "not less" and "greater or equal" agree).
+ * `tmin` is taken through a scalar pair when it is a literal of the caller (the integrators' 0.001), else per lane. */
+template <int TYPE, bool WEXIT>
+RT_DEV void run_rect_test_x(Real a0, Real a1, Real b0, Real b1, Real k, int ref, V3 o, V3 d, const RayDiv& q, Real tmin,
+                            Real& tmax, int& hit_ref) {
+    const Real ok = TYPE == RTR_NODE_XY_RECT ? o.z : (TYPE == RTR_NODE_XZ_RECT ? o.y : o.x);
+    const Real dk = TYPE == RTR_NODE_XY_RECT ? d.z : (TYPE == RTR_NODE_XZ_RECT ? d.y : d.x);
+    const Real rk = TYPE == RTR_NODE_XY_RECT ? q.rz : (TYPE == RTR_NODE_XZ_RECT ? q.ry : q.rx);
+    const Real oa = TYPE == RTR_NODE_YZ_RECT ? o.y : o.x, da = TYPE == RTR_NODE_YZ_RECT ? d.y : d.x;
+    const Real ob = TYPE == RTR_NODE_XY_RECT ? o.y : o.z, db = TYPE == RTR_NODE_XY_RECT ? d.y : d.z;
+    Real n, t, e, u;
+    unsigned long long save;
+/* TMIN: constraint of the t_min operand ("s": scalar pair, "v": per lane); BRANCH: the wave-level exit of shadow rays (no
+ * lane reaches the plane inside its interval) or nothing */
+#define RT_RECT_X(TMIN, BRANCH)                                                                                          \
+    asm volatile("v_add_f64 %[n], %[k], -%[ok]\n\t"                                                                     \
+                 "v_mul_f64 %[t], %[n], %[rk]\n\t"                                                                       \
+                 "v_fma_f64 %[e], -%[dk], %[t], %[n]\n\t"                                                                \
+                 "v_fma_f64 %[t], %[e], %[rk], %[t]\n\t"                                                                 \
+                 "s_mov_b64 %[save], exec\n\t"                                                                           \
+                 "v_cmpx_ngt_f64 vcc, %[tmin], %[t]\n\t"                                                                 \
+                 "v_cmpx_ngt_f64 vcc, %[t], %[tmax]\n\t" BRANCH                                                          \
+                 "v_mul_f64 %[u], %[t], %[da]\n\t"                                                                       \
+                 "v_add_f64 %[u], %[oa], %[u]\n\t"                                                                       \
+                 "v_cmpx_ngt_f64 vcc, %[a0], %[u]\n\t"                                                                   \
+                 "v_cmpx_nlt_f64 vcc, %[a1], %[u]\n\t"                                                                   \
+                 "v_mul_f64 %[u], %[t], %[db]\n\t"                                                                       \
+                 "v_add_f64 %[u], %[ob], %[u]\n\t"                                                                       \
+                 "v_cmpx_ngt_f64 vcc, %[b0], %[u]\n\t"                                                                   \
+                 "v_cmpx_nlt_f64 vcc, %[b1], %[u]\n\t"                                                                   \
+                 "v_mov_b64 %[tmax], %[t]\n\t"                                                                           \
+                 "v_mov_b32 %[hit], %[ref]\n"                                                                             \
+                 ".Lrx%=:\n\t"                                                                                           \
+                 "s_mov_b64 exec, %[save]"                                                                                 \
+                 : [n] "=&v"(n), [t] "=&v"(t), [e] "=&v"(e), [u] "=&v"(u), [save] "=&s"(save), [tmax] "+v"(tmax),             \
+                   [hit] "+v"(hit_ref)                                                                                     \
+                 : [k] "s"(k), [ok] "v"(ok), [dk] "v"(dk), [rk] "v"(rk), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob),             \
+                   [db] "v"(db), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1), [ref] "s"(ref), [tmin] TMIN(tmin)    \
+                 : "vcc")
+    if (__builtin_constant_p(tmin)) {
+        if (WEXIT)
+            RT_RECT_X("s", "s_cbranch_execz .Lrx%=\n\t");
+        else
+            RT_RECT_X("s", "");
+    } else {
+        if (WEXIT)
+            RT_RECT_X("v", "s_cbranch_execz .Lrx%=\n\t");
+        else
+            RT_RECT_X("v", "");
+    }
+#undef RT_RECT_X
+}
+#ifndef RTR_RECT_ASM
+#define RTR_RECT_ASM 1
+#endif
+template <int TYPE, bool WEXIT, bool SHARED>
+RT_DEV void run_rect(Real a0, Real a1, Real b0, Real b1, Real k, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
+                     int& hit_ref) {
+    if (RTR_RECT_ASM && SHARED && !q.guard)
+        run_rect_test_x<TYPE, WEXIT>(a0, a1, b0, b1, k, ref, o, d, q, tmin, tmax, hit_ref);
+    else
+        run_rect_test<TYPE, WEXIT, SHARED>(a0, a1, b0, b1, k, ref, o, d, q, tmin, tmax, hit_ref);
+}
 template <int TYPE, bool WEXIT, bool SHARED>
 RT_DEV void run_rects(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
                       int& hit_ref) {
@@ -900,10 +980,10 @@ RT_DEV void run_rects(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d,
     for (; k + 1 < cnt; k += 2, p += 10) { /* two records, one scalar-load round trip */
         const Real f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3], f4 = p[4];
         const Real g0 = p[5], g1 = p[6], g2 = p[7], g3 = p[8], g4 = p[9];
-        run_rect_test<TYPE, WEXIT, SHARED>(f0, f1, f2, f3, f4, ref + k, o, d, q, tmin, tmax, hit_ref);
-        run_rect_test<TYPE, WEXIT, SHARED>(g0, g1, g2, g3, g4, ref + k + 1, o, d, q, tmin, tmax, hit_ref);
+        run_rect<TYPE, WEXIT, SHARED>(f0, f1, f2, f3, f4, ref + k, o, d, q, tmin, tmax, hit_ref);
+        run_rect<TYPE, WEXIT, SHARED>(g0, g1, g2, g3, g4, ref + k + 1, o, d, q, tmin, tmax, hit_ref);
     }
-    if (k < cnt) run_rect_test<TYPE, WEXIT, SHARED>(p[0], p[1], p[2], p[3], p[4], ref + k, o, d, q, tmin, tmax, hit_ref);
+    if (k < cnt) run_rect<TYPE, WEXIT, SHARED>(p[0], p[1], p[2], p[3], p[4], ref + k, o, d, q, tmin, tmax, hit_ref);
 }
 template <bool SHARED>
 RT_DEV void run_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
@@ -951,6 +1031,55 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
         }
         ref += cnt;
     }
+}
+
+/* ---- leaf references of a box tree (per-lane records) ---------------------------------------------------------- */
+RT_DEV FLeaf load_leaf(const FLeaf* base, int ref) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const __attribute__((address_space(1))) u64x2* q = (const __attribute__((address_space(1))) u64x2*)(unsigned long long)(base + ref);
+    const u64x2 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+    FLeaf L;
+    L.f[0] = __longlong_as_double(w0.x), L.f[1] = __longlong_as_double(w0.y);
+    L.f[2] = __longlong_as_double(w1.x), L.f[3] = __longlong_as_double(w1.y);
+    L.f[4] = __longlong_as_double(w2.x), L.f[5] = __longlong_as_double(w2.y);
+    L.type = (int)(w3.x & 0xffffffffu), L.tag = (int)(w3.x >> 32);
+    L.pad[0] = L.pad[1] = 0;
+    return L;
+}
+/* the references [r0, r1) of one leaf */
+template <bool TIES, bool WEXIT, bool ANY>
+RT_DEV bool leaf_refs(const DScene& sc, int r0, int r1, V3 o, V3 d, Real time, Real tmin, Real& tmax, int& hit_ref, int& order) {
+    for (int r = r0; r < r1; ++r) {
+        const FLeaf L = load_leaf(sc.fleaf, r);
+        const int type = L.type;
+        Real t;
+        bool hit;
+        if (type >= RTR_NODE_XY_RECT) {
+            rtr_node n; /* the fields rect_hit_t reads */
+            n.f[0] = L.f[0], n.f[1] = L.f[1], n.f[2] = L.f[2], n.f[3] = L.f[3];
+            n.f[4] = L.f[4];
+            Real a, b;
+            hit = rect_hit_t<WEXIT, false>(n, type, o, d, raydiv_none(), tmin, tmax, t, a, b);
+        } else if (type == RTR_NODE_SPHERE) {
+            hit = sphere_hit_t(mk(L.f[0], L.f[1], L.f[2]), L.f[3], o, d, tmin, tmax, t);
+        } else {
+            const rtr_node n = ld_const(sc.fprim, r);
+            V3 center;
+            Real radius;
+            sphere_geom(n, type, time, center, radius);
+            hit = sphere_hit_t(center, radius, o, d, tmin, tmax, t);
+        }
+        if (!hit) continue;
+        if (TIES && (L.tag & RT_TIE_FLAG)) { /* see fast_ref_hit */
+            const int visit = L.tag & ~RT_TIE_FLAG;
+            if (t == tmax && visit < order) continue;
+            order = visit;
+        }
+        tmax = t;
+        hit_ref = r;
+        if (ANY) return true;
+    }
+    return false;
 }
 
 #ifndef RTR_TREE_SHARED
@@ -1011,15 +1140,9 @@ __device__ __forceinline__ bool scan_instance(const DScene& sc, const FInst& I, 
         RT_REGION(WEXIT ? RG_SH_LEAVES : RG_LEAVES);
         const int code = -1 - node;
         const int r0 = code >> 3, r1 = r0 + (code & 7) + 1;
-        for (int r = r0; r < r1; ++r) {
-            Real t;
-            if (fast_ref_hit<TREES, WEXIT, SHARED && RTR_TREE_SHARED>(sc, r, lo, ld, q, time, tmin, tmax, t, order)) {
-                tmax = t;
-                tmax_f = float_above(t);
-                hit_ref = r;
-                if (ANY) return true;
-            }
-        }
+        const int before = hit_ref;
+        if (leaf_refs<TREES, WEXIT, ANY>(sc, r0, r1, lo, ld, time, tmin, tmax, hit_ref, order)) return true;
+        if (hit_ref != before) tmax_f = float_above(tmax);
         node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
     }
     return false;

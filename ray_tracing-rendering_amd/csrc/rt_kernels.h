@@ -451,6 +451,43 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_shared_div(unsigned long lon
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
 }
 
+/* rtr_test_issue_rates: shader cycles per wave-instruction, one instruction class per launch.  Every wave runs
+ * `iters` trips of 32 independent instructions of the class between two s_memtime reads; with four waves on each SIMD
+ * (grid = 4 workgroups per CU) the quotient cycles x 1 / (32 iters) of a wave is four times the SIMD's cost per
+ * instruction when the class is bound by its pipe, and the single-wave issue cost when it is not.  out[0] += cycles of
+ * every wave, out[1] += waves. */
+#define RT_REP32(S) S S S S S S S S S S S S S S S S S S S S S S S S S S S S S S S S
+template <int KIND>
+__global__ void __launch_bounds__(RTR_BLOCK) k_test_issue_rate(unsigned long long* out, int iters, double seed) {
+    double a = seed + threadIdx.x, b = seed * 0.5, c = 1.0 / (seed + 3.0), d = seed;
+    float fa = (float)a, fb = (float)b, fc = (float)c;
+    int ia = threadIdx.x, ib = 3;
+    unsigned long long m = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 0) asm volatile(RT_REP32("v_fma_f64 %0, %1, %2, %1\n") : "+v"(d) : "v"(b), "v"(c));
+        if (KIND == 1) asm volatile(RT_REP32("v_add_f64 %0, %1, %2\n") : "+v"(d) : "v"(b), "v"(c));
+        if (KIND == 2) asm volatile(RT_REP32("v_mul_f64 %0, %1, %2\n") : "+v"(d) : "v"(b), "v"(c));
+        if (KIND == 3) asm volatile(RT_REP32("v_rcp_f64 %0, %1\n") : "+v"(d) : "v"(b));
+        if (KIND == 4) asm volatile(RT_REP32("v_rsq_f64 %0, %1\n") : "+v"(d) : "v"(b));
+        if (KIND == 5) asm volatile(RT_REP32("v_cmp_lt_f64 %0, %1, %2\n") : "=s"(m) : "v"(b), "v"(c));
+        if (KIND == 6) asm volatile(RT_REP32("v_cndmask_b32 %0, %1, %2, vcc\n") : "+v"(ia) : "v"(ib), "v"(ia) : "vcc");
+        if (KIND == 7) asm volatile(RT_REP32("v_mov_b32 %0, %1\n") : "+v"(ia) : "v"(ib));
+        if (KIND == 8) asm volatile(RT_REP32("v_fma_f32 %0, %1, %2, %1\n") : "+v"(fa) : "v"(fb), "v"(fc));
+        if (KIND == 9) asm volatile(RT_REP32("s_and_b64 %0, %0, exec\n") : "+s"(m) : : "scc");
+        if (KIND == 10) asm volatile(RT_REP32("v_div_scale_f64 %0, vcc, %1, %2, %1\n") : "+v"(d) : "v"(b), "v"(c) : "vcc");
+        if (KIND == 11) asm volatile(RT_REP32("v_div_fixup_f64 %0, %1, %2, %1\n") : "+v"(d) : "v"(b), "v"(c));
+        if (KIND == 12) /* the rectangle test's mix: one compare into a scalar pair and the scalar AND that uses it */
+            asm volatile(RT_REP32("v_cmp_lt_f64 %0, %1, %2\ns_and_b64 %0, %0, exec\n") : "=s"(m) : "v"(b), "v"(c) : "scc");
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (d == 12345.678 || fa == 1.5f || ia == -77 || m == 0x1234567ull) out[2] = 1; /* keep the results alive */
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], t1 - t0);
+        atomicAdd(&out[1], 1ull);
+    }
+}
+
 __global__ void __launch_bounds__(RTR_BLOCK) k_stream8(const double* __restrict__ in, double* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * RTR_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * RTR_BLOCK)
         out[i] = in[i] + 1.0;

@@ -41,7 +41,7 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan, b_fleaf;
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool force_exact = false;
@@ -617,7 +617,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_done, &c->b_stats, &c->b_cancel, &c->b_test, &c->b_stage,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit, &c->b_fscan};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit, &c->b_fscan, &c->b_fleaf};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -808,6 +808,10 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
             }
         }
         if ((rc = upload(c, c->b_fprim, prims.data(), sizeof(rtr_node) * prims.size()))) return rc;
+        {
+            const std::vector<FLeaf> leaves = rtc::build_leaf_records(cs, prims);
+            if ((rc = upload(c, c->b_fleaf, leaves.data(), sizeof(FLeaf) * leaves.size()))) return rc;
+        }
         rtc::build_scan_runs(cs, prims);
         if ((rc = upload(c, c->b_fscan, cs.scan.data(), sizeof(double) * cs.scan.size()))) return rc;
         if ((rc = upload(c, c->b_finst, cs.inst.data(), sizeof(FInst) * cs.inst.size()))) return rc;
@@ -821,6 +825,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fref = static_cast<const FRef*>(c->b_fref.p);
     d.fprim = static_cast<const rtr_node*>(c->b_fprim.p);
     d.fscan = static_cast<const double*>(c->b_fscan.p);
+    d.fleaf = static_cast<const FLeaf*>(c->b_fleaf.p);
     d.fexit = static_cast<const int32_t*>(c->b_fexit.p);
     d.fbvh = static_cast<const FBvh*>(c->b_fbvh.p);
     d.fsub = static_cast<const FSub*>(c->b_fsub.p);
@@ -1219,6 +1224,32 @@ int rtr_test_sincos_exhaustive(rtr_context* c, uint64_t* mismatches) {
     HIPCHK(c, hipMemcpyAsync(&h, c->b_test.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *mismatches = h;
+    return RTR_OK;
+}
+
+int rtr_test_issue_rates(rtr_context* c, double* cycles_per_inst, int n) {
+    if (!c || !cycles_per_inst || n < 0) return RTR_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = ensure(c, c->b_test, 32);
+    if (rc) return rc;
+    auto* d = static_cast<unsigned long long*>(c->b_test.p);
+    const int iters = 4096;
+    const dim3 grid((unsigned)(c->n_cus * 4));
+    for (int k = 0; k < n && k < 13; ++k) {
+        HIPCHK(c, hipMemsetAsync(d, 0, 32, c->stream));
+#define RTR_RATE(K) case K: hipLaunchKernelGGL(k_test_issue_rate<K>, grid, dim3(RTR_BLOCK), 0, c->stream, d, iters, 1.25); break
+        switch (k) {
+            RTR_RATE(0); RTR_RATE(1); RTR_RATE(2); RTR_RATE(3); RTR_RATE(4); RTR_RATE(5); RTR_RATE(6);
+            RTR_RATE(7); RTR_RATE(8); RTR_RATE(9); RTR_RATE(10); RTR_RATE(11); RTR_RATE(12);
+        }
+#undef RTR_RATE
+        HIPCHK(c, hipGetLastError());
+        unsigned long long h[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        cycles_per_inst[k] = h[1] ? (double)h[0] / (double)h[1] / (32.0 * iters * (k == 12 ? 2 : 1)) : 0.0;
+    }
     return RTR_OK;
 }
 

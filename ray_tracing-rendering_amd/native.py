@@ -22,7 +22,7 @@ EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "
            "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_synchronize", "rtr_cancel",
            "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
            "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order", "rtr_test_stream8",
-           "rtr_test_sincos_exhaustive", "rtr_test_shared_division")
+           "rtr_test_sincos_exhaustive", "rtr_test_shared_division", "rtr_test_issue_rates")
 
 
 class SceneInfoC(C.Structure):
@@ -81,6 +81,8 @@ def lib():
     L.rtr_test_reference_order.argtypes = [vp, C.c_int]
     L.rtr_test_stream8.argtypes = [vp, C.c_int64, C.c_int]
     L.rtr_test_sincos_exhaustive.argtypes = [vp, C.POINTER(C.c_uint64)]
+    if hasattr(L, "rtr_test_issue_rates"):
+        L.rtr_test_issue_rates.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     if hasattr(L, "rtr_test_shared_division"):  # absent from older builds used through RTR_HIP_LIBRARY
         L.rtr_test_shared_division.argtypes = [vp, C.POINTER(C.c_uint64)]
     if L.rtr_abi_version() != A.RTR_ABI_VERSION:
@@ -208,6 +210,15 @@ class Context:
         n = C.c_uint64(0)
         self._chk(self._L.rtr_test_sincos_exhaustive(self._h, C.byref(n)))
         return int(n.value)
+
+    ISSUE_CLASSES = ("v_fma_f64", "v_add_f64", "v_mul_f64", "v_rcp_f64", "v_rsq_f64", "v_cmp_lt_f64", "v_cndmask_b32",
+                     "v_mov_b32", "v_fma_f32", "s_and_b64", "v_div_scale_f64", "v_div_fixup_f64", "v_cmp_f64+s_and_b64")
+
+    def issue_rates(self):
+        """Shader cycles per wave-instruction and class with four waves on every SIMD (include/rtr_hip_test.h)."""
+        out = (C.c_double * len(self.ISSUE_CLASSES))()
+        self._chk(self._L.rtr_test_issue_rates(self._h, out, len(self.ISSUE_CLASSES)))
+        return dict(zip(self.ISSUE_CLASSES, [float(x) for x in out]))
 
     def shared_division_mismatches(self):
         """2^32 operand pairs: how many quotients of the shared-reciprocal division differ from n / d (include/rtr_hip_test.h)."""
