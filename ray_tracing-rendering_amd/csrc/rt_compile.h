@@ -618,22 +618,48 @@ inline void rtc::build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>&
         I.runs = 0;
         if (I.bvh_root >= 0 || I.n_ref == 0) continue;
         std::vector<std::pair<int, int>> runs; /* type, count */
+        std::vector<double> data;
         bool ok = true;
-        for (int r = I.ref_first; r < I.ref_first + I.n_ref && ok; ++r) {
+        const int kBox = RTR_NODE_SPHERE + RT_RUN_BOX;
+        auto same = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0; };
+        /* the six references from r on are the sides of one box, in box.h's order and with its extents */
+        auto box_at = [&](int r) {
+            if (r + 6 > I.ref_first + I.n_ref) return false;
+            const rtr_node* p = &prims[r];
+            static const int want_type[6] = {RTR_NODE_XY_RECT, RTR_NODE_XY_RECT, RTR_NODE_XZ_RECT,
+                                             RTR_NODE_XZ_RECT, RTR_NODE_YZ_RECT, RTR_NODE_YZ_RECT};
+            for (int k = 0; k < 6; ++k)
+                if (p[k].type != want_type[k] || (p[k].reserved & RT_TIE_FLAG)) return false;
+            const double x0 = p[0].f[0], x1 = p[0].f[1], y0 = p[0].f[2], y1 = p[0].f[3], z1 = p[0].f[4], z0 = p[1].f[4];
+            const double want[6][5] = {{x0, x1, y0, y1, z1}, {x0, x1, y0, y1, z0}, {x0, x1, z0, z1, y1},
+                                       {x0, x1, z0, z1, y0}, {y0, y1, z0, z1, x1}, {y0, y1, z0, z1, x0}};
+            for (int k = 0; k < 6; ++k)
+                for (int c = 0; c < 5; ++c)
+                    if (!same(p[k].f[c], want[k][c])) return false;
+            return true;
+        };
+        for (int r = I.ref_first; r < I.ref_first + I.n_ref && ok;) {
             const rtr_node& n = prims[r];
             if (n.reserved & RT_TIE_FLAG) ok = false;
-            if (runs.empty() || runs.back().first != n.type || runs.back().second == 127) runs.push_back({n.type, 0});
+            const bool box = box_at(r);
+            const int type = box ? kBox : n.type;
+            if (runs.empty() || runs.back().first != type || runs.back().second == 127) runs.push_back({type, 0});
             ++runs.back().second;
+            if (box) {
+                const double rec[6] = {n.f[0], n.f[1], n.f[2], n.f[3], prims[r + 1].f[4], n.f[4]}; /* x0 x1 y0 y1 z0 z1 */
+                data.insert(data.end(), rec, rec + 6);
+                r += 6;
+            } else {
+                const int nf = n.type == RTR_NODE_SPHERE ? 4 : (n.type == RTR_NODE_MOVING_SPHERE ? 9 : 5);
+                data.insert(data.end(), n.f, n.f + nf);
+                r += 1;
+            }
         }
         if (!ok || (int)runs.size() > RT_INST_RUNS_MAX) continue;
         I.scan_first = (int32_t)cs.scan.size();
         for (size_t k = 0; k < runs.size(); ++k)
             I.runs |= (uint64_t)((runs[k].first - RTR_NODE_SPHERE) << 7 | runs[k].second) << (10 * k);
-        for (int r = I.ref_first; r < I.ref_first + I.n_ref; ++r) {
-            const rtr_node& n = prims[r];
-            const int nf = n.type == RTR_NODE_SPHERE ? 4 : (n.type == RTR_NODE_MOVING_SPHERE ? 9 : 5);
-            cs.scan.insert(cs.scan.end(), n.f, n.f + nf);
-        }
+        cs.scan.insert(cs.scan.end(), data.begin(), data.end());
         I.flags |= RT_INST_RUNS;
     }
     cs.scan.resize(cs.scan.size() + 16, 0.0); /* the two-records-per-trip loads never leave the array */

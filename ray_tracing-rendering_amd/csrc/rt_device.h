@@ -985,6 +985,23 @@ RT_DEV void run_rects(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d,
     }
     if (k < cnt) run_rect<TYPE, WEXIT, SHARED>(p[0], p[1], p[2], p[3], p[4], ref + k, o, d, q, tmin, tmax, hit_ref);
 }
+/* A `box` (geometry/box.h:31-47): its six sides, in the order of its hittable_list, from ONE record x0 x1 y0 y1 z0 z1 --
+ * one round trip and no per-run overhead for what were three runs of two; the tests are the rectangle tests above, one
+ * after the other (hittable_list.h:33-47). */
+#define RT_RUN_BOX 5 /* run type code (types are stored minus RTR_NODE_SPHERE) */
+template <bool WEXIT, bool SHARED>
+RT_DEV void run_boxes(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
+                      int& hit_ref) {
+    for (int k = 0; k < cnt; ++k, p += 6, ref += 6) {
+        const Real x0 = p[0], x1 = p[1], y0 = p[2], y1 = p[3], z0 = p[4], z1 = p[5];
+        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED>(x0, x1, y0, y1, z1, ref, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED>(x0, x1, y0, y1, z0, ref + 1, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED>(x0, x1, z0, z1, y1, ref + 2, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED>(x0, x1, z0, z1, y0, ref + 3, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED>(y0, y1, z0, z1, x1, ref + 4, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED>(y0, y1, z0, z1, x0, ref + 5, o, d, q, tmin, tmax, hit_ref);
+    }
+}
 template <bool SHARED>
 RT_DEV void run_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
                         int& hit_ref) {
@@ -1012,7 +1029,7 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
 #pragma nounroll
     for (uint64_t runs = I.runs; runs != 0; runs >>= 10) {
         const int type = RTR_NODE_SPHERE + (int)((runs >> 7) & 7), cnt = (int)(runs & 127);
-        RT_REGION(type >= RTR_NODE_XY_RECT ? (WEXIT ? RG_SH_RECTS : RG_RECTS) : (WEXIT ? RG_SH_SPHERES : RG_SPHERES));
+        RT_REGION(type >= RTR_NODE_XY_RECT ? (WEXIT ? RG_SH_RECTS : RG_RECTS) : (WEXIT ? RG_SH_SPHERES : RG_SPHERES)); /* boxes count as rects */
         if (type == RTR_NODE_XY_RECT) {
             run_rects<RTR_NODE_XY_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 5 * cnt;
@@ -1022,6 +1039,10 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
         } else if (type == RTR_NODE_YZ_RECT) {
             run_rects<RTR_NODE_YZ_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 5 * cnt;
+        } else if (type == RTR_NODE_SPHERE + RT_RUN_BOX) {
+            run_boxes<WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            p += 6 * cnt;
+            ref += 5 * cnt; /* six references per box */
         } else if (type == RTR_NODE_SPHERE) {
             run_spheres<SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 4 * cnt;
