@@ -1685,6 +1685,38 @@ __device__ __forceinline__ V3 pbr_eval(const MatCtx& c, V3 wo, V3 wi) {
     V3 diffuse = divs(mul(kD, base_color), RT_PI);
     return add(diffuse, specular);
 }
+/* PBRMaterial::eval and ::pdf of the same pair of directions (the light sample of sample_lights_mis, the BSDF sample of
+ * PBRMaterial::sample: material.h:296-298, mis_path_integrator.h:215-224): the half vector, D, N.H and H.V are the same
+ * expressions in both (material.h:317-331, :356-373) -- computed once here, each result as above */
+__device__ __forceinline__ void pbr_eval_pdf(const MatCtx& c, V3 wo, V3 wi, V3& f, Real& pdf) {
+    const V3 N = c.N;
+    const Real NdotL = dot(N, wi);
+    f = mk(0, 0, 0), pdf = 0;
+    if (NdotL <= 0) return; /* material.h:312 and :349 */
+    const Real rough = c.rough, metal = c.metal;
+    const V3 H = unit(add(wo, wi));
+    const Real D = distribution_ggx(N, H, rough);
+    const Real NdotH = maxd(dot(N, H), 0.0);
+    const Real HdotV = maxd(dot(H, wo), 0.0);
+    const Real pdf_diff = NdotL / RT_PI;
+    const Real pdf_spec = (D * NdotH) / (4.0 * HdotV + 0.0001);
+    pdf = 0.5 * pdf_diff + 0.5 * pdf_spec;
+    const Real NdotV = dot(N, wo);
+    if (NdotV <= 0) return; /* material.h:349 */
+    const V3 base_color = c.albedo;
+    V3 F0 = mk(0.04, 0.04, 0.04);
+    const V3 metal_vec = mk(metal, metal, metal);
+    F0 = add(mul(sub(mk(1.0, 1.0, 1.0), metal_vec), F0), mul(metal_vec, base_color));
+    const V3 F = fresnel_schlick(HdotV, F0);
+    const Real G = geometry_smith(N, wo, wi, rough);
+    const V3 numerator = scl(D * G, F);
+    const Real denominator = 4.0 * NdotV * NdotL + 0.0001;
+    const V3 specular = divs(numerator, denominator);
+    V3 kD = sub(mk(1.0, 1.0, 1.0), F);
+    kD = scl(1.0 - metal, kD);
+    const V3 diffuse = divs(mul(kD, base_color), RT_PI);
+    f = add(diffuse, specular);
+}
 RT_DEV Real reflectance(Real cosine, Real ref_idx) { /* material.h:199-203 */
     Real r0 = (1 - ref_idx) / (1 + ref_idx);
     r0 = r0 * r0;
@@ -1749,8 +1781,7 @@ __device__ __forceinline__ bool pbr_sample(const MatCtx& c, V3 wo, BSDFSample& s
         s.wi = unit(L);
     }
     s.is_specular = false;
-    s.pdf = pbr_pdf(c, wo, s.wi);
-    s.f = pbr_eval(c, wo, s.wi);
+    pbr_eval_pdf(c, wo, s.wi, s.f, s.pdf);
     if (s.pdf < 1e-6) return false;
     return true;
 }
@@ -1815,6 +1846,16 @@ RT_DEV Real mat_pdf(const MatCtx& c, const Hit& rec, V3 wo, V3 wi) {
     }
     if (MS != RT_MS_LEAN && c.type == RTR_MAT_PBR) return pbr_pdf(c, wo, wi);
     return 0.0;
+}
+/* material::eval and material::pdf of one pair of directions */
+template <int MS = RT_MS_FULL>
+RT_DEV void mat_eval_pdf(const MatCtx& c, const Hit& rec, V3 wo, V3 wi, V3& f, Real& pdf) {
+    if (MS != RT_MS_LEAN && c.type == RTR_MAT_PBR) {
+        pbr_eval_pdf(c, wo, wi, f, pdf);
+        return;
+    }
+    f = mat_eval<MS>(c, wo, wi);
+    pdf = mat_pdf<MS>(c, rec, wo, wi);
 }
 /* legacy material::scatter(r_in, rec, attenuation, scattered): new ray = (rec.p, dir, r_in.time) */
 template <int MS = RT_MS_FULL>
@@ -2226,7 +2267,12 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, const M
             ls = light_sample<MS>(li, rec.p, ux, uy, rng, sc.image_bytes);
         }
         if (ls.pdf > 0 && len2(ls.Li) > 0) {
-            V3 f = mat_eval<MS>(mc, wo, ls.wi);
+            V3 f;
+            Real bsdf_pdf = 0;
+            if (INTEG == RTR_INTEGRATOR_MIS && !ls.is_delta)
+                mat_eval_pdf<MS>(mc, rec, wo, ls.wi, f, bsdf_pdf); /* mis_path_integrator.h:215, :223 */
+            else
+                f = mat_eval<MS>(mc, wo, ls.wi);
             Real cos_theta = __builtin_fabs(dot(ls.wi, rec.n));
             V3 L_direct;
             if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:125-139 */
@@ -2238,7 +2284,6 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, const M
             } else if (ls.is_delta) { /* mis_path_integrator.h:219-221: no BSDF sample can hit a delta light */
                 L_direct = divs(scl(cos_theta, mul(f, ls.Li)), light_select_pdf);
             } else { /* mis_path_integrator.h:222-229 */
-                Real bsdf_pdf = mat_pdf<MS>(mc, rec, wo, ls.wi);
                 Real lpdf = ls.pdf * light_select_pdf;
                 Real mis_weight = power_heuristic(lpdf, bsdf_pdf);
                 L_direct = divs(scl(mis_weight, scl(cos_theta, mul(f, ls.Li))), lpdf);
