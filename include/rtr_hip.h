@@ -305,6 +305,16 @@ int rtr_plan_chunks(rtr_context* ctx, const rtr_render_params* params);
  * max_depth, rr_start_depth and flags apply; region, tiles, chunks and pipeline do not.  Host arrays; blocking. */
 int rtr_li_samples(rtr_context* ctx, const rtr_render_params* params, const int32_t* ijs, double* L, int64_t n);
 
+/* The same for ARBITRARY rays (Integrator::Li takes any `ray`: renderer/integrator.h:12-19): ray k starts at
+ * origin with direction (not normalised by the library, like the reference's), time, and the xorshift32 state
+ * (core/rtweekend.h:24-34; must not be 0) the reference's thread-local generator would hold when Li is entered --
+ * for a camera ray that is the state after camera::get_ray.  L[3k..3k+2] receives the radiance. */
+typedef struct rtr_li_ray {
+    double origin[3], direction[3], time;
+    uint32_t rng_state, pad;
+} rtr_li_ray;
+int rtr_li_rays(rtr_context* ctx, const rtr_render_params* params, const rtr_li_ray* rays, double* L, int64_t n);
+
 /* Wait for everything queued on the context stream. */
 int rtr_synchronize(rtr_context* ctx);
 
@@ -330,6 +340,27 @@ const char* rtr_last_error(const rtr_context* ctx);
  * xorshift32 state (core/rtweekend.h:24-34) used for sample `s` of pixel
  * (i, j) under render seed `seed`; never 0. */
 uint32_t rtr_sample_seed(uint32_t seed, int32_t image_width, int32_t i, int32_t j, int32_t s);
+
+/* Facts rtr_upload_scene() derives from a scene, and the host-only check it runs before touching the GPU. */
+typedef struct rtr_scene_info {
+    int32_t stack_words; /* LDS traversal-stack words per lane the reference-order traversal needs */
+    int32_t has_media;   /* constant_medium present: RNG is consumed inside traversal */
+    int32_t needs_uv;    /* some texture reads (u,v) */
+    int32_t graph_depth; /* longest root-to-leaf chain of hittables */
+    int32_t fast_ok;     /* a compiled scene exists (no media): the order-free traversal is the default */
+    int32_t fast_instances, fast_refs, fast_stack_words;
+    int32_t compiled_subtrees; /* media scenes: media-free subtrees compiled inside the reference-order walk */
+    int32_t program_steps;     /* media scenes: steps of the ray-cast program (0: media not directly under the root list) */
+    int32_t inverted_boxes;    /* spheres with a negative radius (hollow glass): sphere::bounding_box (sphere.h:62-66)
+                                  then has min > max, the bvh_node boxes built from it do not enclose the sphere,
+                                  and which rays still reach it depends on the reference's visiting order */
+    int32_t reserved[1];
+} rtr_scene_info;
+
+/* Host-only: the checks rtr_upload_scene() runs before touching the GPU.  Returns RTR_OK,
+ * RTR_ERR_INVALID or RTR_ERR_UNSUPPORTED; `msg` (may be NULL) receives the reason. */
+int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* msg, size_t msg_cap);
+
 
 #ifdef __cplusplus
 }

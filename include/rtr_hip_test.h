@@ -1,9 +1,9 @@
 /*
- * rtr_hip_test.h -- auxiliary entry points of librtr_hip.so used by the parity tests:
- * a host-only scene check, and device unit kernels that run the library's own device
- * functions over golden-vector records (include/rtr_testrec.h), one lane per record.
- * They exist so tests can compare the HIP path with the oracle below the whole-image
- * level; a renderer integration only needs rtr_hip.h.
+ * rtr_hip_test.h -- entry points of librtr_hip_test.so, a SEPARATE library next to librtr_hip.so (it links against
+ * it): device unit kernels that run the product's own device functions (csrc/rt_device.h) over golden-vector records
+ * (include/rtr_testrec.h), one lane per record, plus counter-calibration and instruction-level checks.  They exist
+ * so tests can compare the HIP path with the oracle below the whole-image level; none of this code is in the
+ * product library, and a renderer integration only needs rtr_hip.h.
  */
 #ifndef RTR_HIP_TEST_H
 #define RTR_HIP_TEST_H
@@ -14,25 +14,6 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-typedef struct rtr_scene_info {
-    int32_t stack_words; /* LDS traversal-stack words per lane the reference-order traversal needs */
-    int32_t has_media;   /* constant_medium present: RNG is consumed inside traversal */
-    int32_t needs_uv;    /* some texture reads (u,v) */
-    int32_t graph_depth; /* longest root-to-leaf chain of hittables */
-    int32_t fast_ok;     /* a compiled scene exists (no media): the order-free traversal is the default */
-    int32_t fast_instances, fast_refs, fast_stack_words;
-    int32_t compiled_subtrees; /* media scenes: media-free subtrees compiled inside the reference-order walk */
-    int32_t program_steps;     /* media scenes: steps of the ray-cast program (0: media not directly under the root list) */
-    int32_t inverted_boxes;    /* spheres with a negative radius (hollow glass): sphere::bounding_box (sphere.h:62-66)
-                                  then has min > max, the bvh_node boxes built from it do not enclose the sphere,
-                                  and which rays still reach it depends on the reference's visiting order */
-    int32_t reserved[1];
-} rtr_scene_info;
-
-/* Host-only: the checks rtr_upload_scene() runs before touching the GPU.  Returns RTR_OK,
- * RTR_ERR_INVALID or RTR_ERR_UNSUPPORTED; `msg` (may be NULL) receives the reason. */
-int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* msg, size_t msg_cap);
 
 /* In-place on HOST arrays of records: inputs are read, outputs overwritten. */
 int rtr_test_hits(rtr_context* ctx, rtr_hit_record* recs, int64_t n);

@@ -40,6 +40,9 @@ CAMERA_DTYPE = np.dtype([("origin", "<f8", (3,)), ("lower_left_corner", "<f8", (
 assert NODE_DTYPE.itemsize == 96 and MATERIAL_DTYPE.itemsize == 64 and TEXTURE_DTYPE.itemsize == 48
 assert PERLIN_DTYPE.itemsize == 9216 and IMAGE_DTYPE.itemsize == 16 and LIGHT_DTYPE.itemsize == 136
 assert CAMERA_DTYPE.itemsize == 192
+LI_RAY_DTYPE = np.dtype([("origin", "<f8", (3,)), ("direction", "<f8", (3,)), ("time", "<f8"), ("rng_state", "<u4"),
+                         ("pad", "<u4")])  # rtr_li_ray
+assert LI_RAY_DTYPE.itemsize == 64
 
 # golden-vector records (rtr_testrec.h, packed)
 LI_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("s", "<i4"), ("rng_exit", "<u4"), ("L", "<f8", (3,)),

@@ -1,6 +1,7 @@
 """In-tree build of the native pieces (no JIT cache: the .so files travel with the tree).
 
   librtr_hip.so   HIP kernels + C ABI, hipcc --offload-arch=gfx950 (cross-compiles without a GPU)
+  librtr_hip_test.so  device unit kernels of the parity tests (include/rtr_hip_test.h); links against librtr_hip.so
   librtr_host.so  C++ host layer: the reference's scene-description API + flattening (g++)
 """
 import os
@@ -36,7 +37,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contra
 # translation units of librtr_hip.so: (object name, source, extra defines); compiled in parallel
 HIP_UNITS = [("capi", "rtr_capi.hip", []), ("mega_mis", "rtr_mega.hip", ["-DRTR_MEGA_GROUP=0"]),
              ("mega_rr_path", "rtr_mega.hip", ["-DRTR_MEGA_GROUP=1"]), ("mega_pbr_nee", "rtr_mega.hip", ["-DRTR_MEGA_GROUP=2"]),
-             ("wavefront", "rtr_wavefront.hip", [])]
+             ("wavefront", "rtr_wavefront.hip", []), ("test", "rtr_test.hip", [])]
 
 
 def build_hip(force=False, verbose=False, extra_flags=()):
@@ -75,7 +76,12 @@ def build_hip(force=False, verbose=False, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=min(len(HIP_UNITS), os.cpu_count() or 1)) as pool:
         results = list(pool.map(compile_unit, HIP_UNITS))
-    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", out], check=True)
+    product = [o for (name, _, _), (o, _) in zip(HIP_UNITS, results) if name != "test"]
+    test_objs = [o for (name, _, _), (o, _) in zip(HIP_UNITS, results) if name == "test"]
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + product + ["-o", out], check=True)
+    # the device unit kernels of the parity tests: a library of their own next to the product (include/rtr_hip_test.h)
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + test_objs +
+                   ["-L" + HERE, "-lrtr_hip", "-Wl,-rpath,$ORIGIN", "-o", os.path.join(HERE, "librtr_hip_test.so")], check=True)
     with open(stamp, "w") as f:
         f.write(flags_now)
     if verbose:

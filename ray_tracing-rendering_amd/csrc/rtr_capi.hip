@@ -8,7 +8,7 @@
 #include "rt_kernels.h"
 #include "rt_launch.h"
 #include "rt_machine.h"
-#include "rtr_hip_test.h"
+#include "rt_debug.h"
 
 #include <atomic>
 #include <cstdio>
@@ -44,7 +44,6 @@ struct rtr_context {
     DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan, b_fleaf;
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
-    bool force_exact = false;
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
     bool quad_lights_only = false;
     bool flat_scene = false; /* compiled scene without box trees and without tie-capable references */
@@ -389,9 +388,9 @@ std::vector<int> owned_tiles(const rtr_render_params& p, int& tiles_x, int& tile
  * for the reference's visiting order */
 int pick_trav(const rtr_context* c, int flags) {
     if (c->info.has_media || c->info.inverted_boxes)
-        return c->info.program_steps > 0 && !c->force_exact && !(flags & RTR_FLAG_REFERENCE_ORDER) ? RT_TRAV_PROGRAM
+        return c->info.program_steps > 0 && !(flags & RTR_FLAG_REFERENCE_ORDER) ? RT_TRAV_PROGRAM
                                                                                                      : RT_TRAV_MEDIA;
-    if (!c->info.fast_ok || c->uv_order_dependent || c->force_exact || (flags & RTR_FLAG_REFERENCE_ORDER))
+    if (!c->info.fast_ok || c->uv_order_dependent || (flags & RTR_FLAG_REFERENCE_ORDER))
         return RT_TRAV_EXACT;
     return c->flat_scene ? RT_TRAV_FLAT : RT_TRAV_FAST;
 }
@@ -1080,86 +1079,36 @@ int rtr_get_stats(rtr_context* c, rtr_render_stats* out) {
 
 const char* rtr_last_error(const rtr_context* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
-/* ---- device unit kernels (rtr_hip_test.h) ---------------------------------------------------- */
-static int test_begin(rtr_context* c, const void* recs, int64_t n, size_t rec_size) {
+/* ---- per-ray entry: Integrator::Li of camera samples or caller-given rays ------------------------------------ */
+static int li_run(rtr_context* c, const rtr_render_params* p, const int32_t* ijs, const rtr_li_ray* rays, LiOut* host_out,
+                  int64_t n) {
     if (!c) return RTR_ERR_INVALID;
-    if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_test_* before rtr_upload_scene");
-    if (!recs || n < 0) return fail(c, RTR_ERR_INVALID, "bad record array");
+    if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_li_* before rtr_upload_scene");
+    if (int prc = params_check(c, p)) return prc;
+    if (n == 0) return RTR_OK;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return upload(c, c->b_test, recs, (size_t)n * rec_size);
-}
-static int test_end(rtr_context* c, void* recs, int64_t n, size_t rec_size) {
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (n) HIPCHK(c, hipMemcpy(recs, c->b_test.p, (size_t)n * rec_size, hipMemcpyDeviceToHost));
-    return RTR_OK;
-}
-static dim3 test_grid(int64_t n) { return dim3((unsigned)((n + RTR_BLOCK - 1) / RTR_BLOCK)); }
-
-int rtr_test_hits(rtr_context* c, rtr_hit_record* recs, int64_t n) {
-    int rc = test_begin(c, recs, n, sizeof *recs);
-    if (rc || n == 0) return rc;
-    DScene ds = c->ds;
-    ds.needs_uv = 1; /* the vectors pin u,v although no flattened texture of these scenes reads them */
-    auto* d = static_cast<rtr_hit_record*>(c->b_test.p);
-    int trav = pick_trav(c, 0);
-    if (trav == RT_TRAV_FLAT) trav = RT_TRAV_FAST; /* same results; one test kernel for both */
-    const size_t lds = stack_bytes(c, trav);
-    if (trav == RT_TRAV_FAST) {
-        if ((rc = set_lds(c, k_test_hits<RT_TRAV_FAST>, lds))) return rc;
-        hipLaunchKernelGGL(k_test_hits<RT_TRAV_FAST>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
-    } else if (trav == RT_TRAV_PROGRAM) {
-        if ((rc = set_lds(c, k_test_hits<RT_TRAV_PROGRAM>, lds))) return rc;
-        hipLaunchKernelGGL(k_test_hits<RT_TRAV_PROGRAM>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
-    } else if (trav == RT_TRAV_MEDIA) {
-        if ((rc = set_lds(c, k_test_hits<RT_TRAV_MEDIA>, lds))) return rc;
-        hipLaunchKernelGGL(k_test_hits<RT_TRAV_MEDIA>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
-    } else {
-        if ((rc = set_lds(c, k_test_hits<RT_TRAV_EXACT>, lds))) return rc;
-        hipLaunchKernelGGL(k_test_hits<RT_TRAV_EXACT>, test_grid(n), dim3(RTR_BLOCK), lds, c->stream, ds, d, (long long)n);
-    }
-    return test_end(c, recs, n, sizeof *recs);
-}
-
-int rtr_test_materials(rtr_context* c, rtr_mat_record* recs, int64_t n) {
-    int rc = test_begin(c, recs, n, sizeof *recs);
-    if (rc || n == 0) return rc;
-    for (int64_t k = 0; k < n; ++k)
-        if (recs[k].material < 0 || recs[k].material >= c->n_materials)
-            return fail(c, RTR_ERR_INVALID, "material index out of range");
-    hipLaunchKernelGGL(k_test_materials, test_grid(n), dim3(RTR_BLOCK), 0, c->stream, c->ds,
-                       static_cast<rtr_mat_record*>(c->b_test.p), (long long)n);
-    return test_end(c, recs, n, sizeof *recs);
-}
-
-int rtr_test_lights(rtr_context* c, rtr_light_record* recs, int64_t n) {
-    int rc = test_begin(c, recs, n, sizeof *recs);
-    if (rc || n == 0) return rc;
-    for (int64_t k = 0; k < n; ++k)
-        if (recs[k].light < 0 || recs[k].light >= c->ds.n_lights) return fail(c, RTR_ERR_INVALID, "light index out of range");
-    hipLaunchKernelGGL(k_test_lights, test_grid(n), dim3(RTR_BLOCK), 0, c->stream, c->ds,
-                       static_cast<rtr_light_record*>(c->b_test.p), (long long)n);
-    return test_end(c, recs, n, sizeof *recs);
-}
-
-int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs, int64_t n) {
-    if (!c) return RTR_ERR_INVALID;
-    if (int prc = params_check(c, p)) return prc;
-    int rc = test_begin(c, recs, n, sizeof *recs);
-    if (rc || n == 0) return rc;
+    const size_t in_bytes = rays ? (size_t)n * sizeof(rtr_li_ray) : (size_t)n * 3 * sizeof(int32_t);
+    const size_t in_pad = (in_bytes + 15) & ~(size_t)15;
+    int rc = ensure(c, c->b_test, in_pad + (size_t)n * sizeof(LiOut));
+    if (rc) return rc;
+    char* base = static_cast<char*>(c->b_test.p);
+    HIPCHK(c, hipMemcpy(base, rays ? (const void*)rays : (const void*)ijs, in_bytes, hipMemcpyHostToDevice));
     RenderK P{};
     P.W = p->image_width, P.H = p->image_height;
     P.spp = p->spp, P.max_depth = p->max_depth, P.rr_start = p->rr_start_depth;
     P.seed = p->seed;
-    auto* d = static_cast<rtr_li_record*>(c->b_test.p);
+    const int32_t* d_ijs = rays ? nullptr : reinterpret_cast<const int32_t*>(base);
+    const rtr_li_ray* d_rays = rays ? reinterpret_cast<const rtr_li_ray*>(base) : nullptr;
+    LiOut* d_out = reinterpret_cast<LiOut*>(base + in_pad);
     int trav = pick_trav(c, p->flags);
-    if (trav == RT_TRAV_FLAT) trav = RT_TRAV_FAST;
+    if (trav == RT_TRAV_FLAT) trav = RT_TRAV_FAST; /* same results; one per-ray kernel for both */
     const size_t lds = stack_bytes(c, trav);
-#define RTR_LAUNCH(I, T)                                                                                        \
-    do {                                                                                                        \
-        if ((rc = set_lds(c, k_test_li<I, T>, lds))) return rc;                                                 \
-        hipLaunchKernelGGL((k_test_li<I, T>), test_grid(n), dim3(RTR_BLOCK), lds, c->stream, c->ds, P, d, (long long)n); \
+    const dim3 grid((unsigned)((n + RTR_BLOCK - 1) / RTR_BLOCK));
+#define RTR_LAUNCH(I, T)                                                                                            \
+    do {                                                                                                            \
+        if ((rc = set_lds(c, k_li<I, T>, lds))) return rc;                                                          \
+        hipLaunchKernelGGL((k_li<I, T>), grid, dim3(RTR_BLOCK), lds, c->stream, c->ds, P, d_ijs, d_rays, d_out, (long long)n); \
     } while (0)
 #define RTR_LAUNCH_T(I)                                        \
     do {                                                       \
@@ -1191,83 +1140,9 @@ int rtr_test_li(rtr_context* c, const rtr_render_params* p, rtr_li_record* recs,
 #undef RTR_LAUNCH_N1
 #undef RTR_LAUNCH_T
 #undef RTR_LAUNCH
-    return test_end(c, recs, n, sizeof *recs);
-}
-
-int rtr_test_stream8(rtr_context* c, int64_t n_doubles, int repeat) {
-    if (!c || n_doubles <= 0 || repeat <= 0) return RTR_ERR_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = ensure(c, c->b_test, (size_t)n_doubles * 16);
-    if (rc) return rc;
-    double* in = static_cast<double*>(c->b_test.p);
-    double* out = in + n_doubles;
-    HIPCHK(c, hipMemsetAsync(in, 0, (size_t)n_doubles * 16, c->stream));
-    for (int r = 0; r < repeat; ++r)
-        hipLaunchKernelGGL(k_stream8, dim3((unsigned)(c->n_cus * 16)), dim3(RTR_BLOCK), 0, c->stream, in, out, (long long)n_doubles);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return RTR_OK;
-}
-
-int rtr_test_sincos_exhaustive(rtr_context* c, uint64_t* mismatches) {
-    if (!c || !mismatches) return RTR_ERR_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = ensure(c, c->b_test, 8);
-    if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->b_test.p, 0, 8, c->stream));
-    hipLaunchKernelGGL(k_test_sincos, dim3((unsigned)(c->n_cus * 16)), dim3(RTR_BLOCK), 0, c->stream,
-                       static_cast<unsigned long long*>(c->b_test.p));
-    HIPCHK(c, hipGetLastError());
-    unsigned long long h = 0;
-    HIPCHK(c, hipMemcpyAsync(&h, c->b_test.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *mismatches = h;
-    return RTR_OK;
-}
-
-int rtr_test_issue_rates(rtr_context* c, double* cycles_per_inst, int n) {
-    if (!c || !cycles_per_inst || n < 0) return RTR_ERR_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = ensure(c, c->b_test, 32);
-    if (rc) return rc;
-    auto* d = static_cast<unsigned long long*>(c->b_test.p);
-    const int iters = 4096;
-    const dim3 grid((unsigned)(c->n_cus * 4));
-    for (int k = 0; k < n && k < 13; ++k) {
-        HIPCHK(c, hipMemsetAsync(d, 0, 32, c->stream));
-#define RTR_RATE(K) case K: hipLaunchKernelGGL(k_test_issue_rate<K>, grid, dim3(RTR_BLOCK), 0, c->stream, d, iters, 1.25); break
-        switch (k) {
-            RTR_RATE(0); RTR_RATE(1); RTR_RATE(2); RTR_RATE(3); RTR_RATE(4); RTR_RATE(5); RTR_RATE(6);
-            RTR_RATE(7); RTR_RATE(8); RTR_RATE(9); RTR_RATE(10); RTR_RATE(11); RTR_RATE(12);
-        }
-#undef RTR_RATE
-        HIPCHK(c, hipGetLastError());
-        unsigned long long h[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        cycles_per_inst[k] = h[1] ? (double)h[0] / (double)h[1] / (32.0 * iters * (k == 12 ? 2 : 1)) : 0.0;
-    }
-    return RTR_OK;
-}
-
-int rtr_test_shared_division(rtr_context* c, uint64_t* mismatches) {
-    if (!c || !mismatches) return RTR_ERR_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = ensure(c, c->b_test, 8);
-    if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->b_test.p, 0, 8, c->stream));
-    const unsigned blocks = 4096, per_thread = (unsigned)((1ull << 32) / ((unsigned long long)blocks * RTR_BLOCK));
-    hipLaunchKernelGGL(k_test_shared_div, dim3(blocks), dim3(RTR_BLOCK), 0, c->stream,
-                       static_cast<unsigned long long*>(c->b_test.p), per_thread);
-    HIPCHK(c, hipGetLastError());
-    unsigned long long h = 0;
-    HIPCHK(c, hipMemcpyAsync(&h, c->b_test.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *mismatches = h;
+    HIPCHK(c, hipMemcpy(host_out, d_out, (size_t)n * sizeof(LiOut), hipMemcpyDeviceToHost));
     return RTR_OK;
 }
 
@@ -1275,25 +1150,53 @@ int rtr_li_samples(rtr_context* c, const rtr_render_params* p, const int32_t* ij
     if (!c) return RTR_ERR_INVALID;
     if (n < 0 || (n > 0 && (!ijs || !L))) return fail(c, RTR_ERR_INVALID, "bad sample / radiance arrays");
     if (int prc = params_check(c, p)) return prc;
-    std::vector<rtr_li_record> recs((size_t)n);
-    for (int64_t k = 0; k < n; ++k) {
-        rtr_li_record r{};
-        r.i = ijs[3 * k], r.j = ijs[3 * k + 1], r.s = ijs[3 * k + 2];
-        if (r.i < 0 || r.i >= p->image_width || r.j < 0 || r.j >= p->image_height || r.s < 0)
+    for (int64_t k = 0; k < n; ++k)
+        if (ijs[3 * k] < 0 || ijs[3 * k] >= p->image_width || ijs[3 * k + 1] < 0 || ijs[3 * k + 1] >= p->image_height ||
+            ijs[3 * k + 2] < 0)
             return fail(c, RTR_ERR_INVALID, "sample outside the image");
-        recs[(size_t)k] = r;
-    }
-    int rc = rtr_test_li(c, p, recs.data(), n); /* the same unit kernel the parity tests drive */
+    std::vector<LiOut> out((size_t)n);
+    int rc = li_run(c, p, ijs, nullptr, out.data(), n);
     if (rc) return rc;
     for (int64_t k = 0; k < n; ++k)
-        for (int q = 0; q < 3; ++q) L[3 * k + q] = recs[(size_t)k].L[q];
+        for (int q = 0; q < 3; ++q) L[3 * k + q] = out[(size_t)k].L[q];
     return RTR_OK;
 }
 
-int rtr_test_reference_order(rtr_context* c, int on) {
+int rtr_li_rays(rtr_context* c, const rtr_render_params* p, const rtr_li_ray* rays, double* L, int64_t n) {
     if (!c) return RTR_ERR_INVALID;
-    c->force_exact = on != 0;
+    if (n < 0 || (n > 0 && (!rays || !L))) return fail(c, RTR_ERR_INVALID, "bad ray / radiance arrays");
+    for (int64_t k = 0; k < n; ++k)
+        if (rays[k].rng_state == 0) return fail(c, RTR_ERR_INVALID, "a xorshift32 state must not be 0 (rtweekend.h:24-34)");
+    std::vector<LiOut> out((size_t)n);
+    int rc = li_run(c, p, nullptr, rays, out.data(), n);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n; ++k)
+        for (int q = 0; q < 3; ++q) L[3 * k + q] = out[(size_t)k].L[q];
     return RTR_OK;
+}
+
+/* ---- the seam librtr_hip_test.so reaches the context through (csrc/rt_debug.h; not part of include/) ------------- */
+int rtr_debug_view_get(rtr_context* c, int flags, rtr_debug_view* v, size_t size) {
+    if (!c || !v || size != sizeof(rtr_debug_view)) return RTR_ERR_INVALID;
+    if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_test_* before rtr_upload_scene");
+    v->ds = c->ds;
+    v->stream = c->stream;
+    v->device = c->device;
+    v->n_cus = c->n_cus;
+    v->n_materials = c->n_materials;
+    int trav = pick_trav(c, flags);
+    if (trav == RT_TRAV_FLAT) trav = RT_TRAV_FAST;
+    v->trav = trav;
+    v->stack_bytes = stack_bytes(c, trav);
+    return RTR_OK;
+}
+int rtr_debug_li(rtr_context* c, const rtr_render_params* p, const int32_t* ijs, rtr_debug_li_out* out, int64_t n) {
+    static_assert(sizeof(rtr_debug_li_out) == sizeof(LiOut), "one layout");
+    if (n < 0 || (n > 0 && (!ijs || !out))) return RTR_ERR_INVALID;
+    return li_run(c, p, ijs, nullptr, reinterpret_cast<LiOut*>(out), n);
+}
+void rtr_debug_set_error(rtr_context* c, const char* msg) {
+    if (c) c->err = msg ? msg : "";
 }
 
 } /* extern "C" */

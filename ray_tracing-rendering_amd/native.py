@@ -17,12 +17,14 @@ _STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR
            A.RTR_ERR_DEVICE: "RTR_ERR_DEVICE", A.RTR_ERR_NO_SCENE: "RTR_ERR_NO_SCENE",
            A.RTR_ERR_CANCELLED: "RTR_ERR_CANCELLED", A.RTR_ERR_NOMEM: "RTR_ERR_NOMEM"}
 
-# every symbol include/rtr_hip.h and include/rtr_hip_test.h declare
+# every symbol include/rtr_hip.h declares (librtr_hip.so) ...
 EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
-           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_synchronize", "rtr_cancel",
-           "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene", "rtr_test_hits",
-           "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order", "rtr_test_stream8",
-           "rtr_test_sincos_exhaustive", "rtr_test_shared_division", "rtr_test_issue_rates")
+           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_li_rays",
+           "rtr_synchronize", "rtr_cancel", "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene")
+# ... and include/rtr_hip_test.h (librtr_hip_test.so: device unit kernels of the parity tests, not part of the product)
+TEST_EXPORTS = ("rtr_test_hits", "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order",
+                "rtr_test_stream8", "rtr_test_sincos_exhaustive", "rtr_test_shared_division", "rtr_test_issue_rates")
+_TEST_LIB = None
 
 
 class SceneInfoC(C.Structure):
@@ -75,20 +77,37 @@ def lib():
     L.rtr_sample_seed.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.rtr_sample_seed.restype = C.c_uint32
     L.rtr_validate_scene.argtypes = [P(A.SceneDescC), P(SceneInfoC), C.c_char_p, C.c_size_t]
-    for name in ("rtr_test_hits", "rtr_test_materials", "rtr_test_lights"):
-        getattr(L, name).argtypes = [vp, vp, C.c_int64]
-    L.rtr_test_li.argtypes = [vp, P(A.RenderParamsC), vp, C.c_int64]
-    L.rtr_test_reference_order.argtypes = [vp, C.c_int]
-    L.rtr_test_stream8.argtypes = [vp, C.c_int64, C.c_int]
-    L.rtr_test_sincos_exhaustive.argtypes = [vp, C.POINTER(C.c_uint64)]
-    if hasattr(L, "rtr_test_issue_rates"):
-        L.rtr_test_issue_rates.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
-    if hasattr(L, "rtr_test_shared_division"):  # absent from older builds used through RTR_HIP_LIBRARY
-        L.rtr_test_shared_division.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rtr_li_rays.argtypes = [vp, P(A.RenderParamsC), vp, vp, C.c_int64]
     if L.rtr_abi_version() != A.RTR_ABI_VERSION:
         raise RtrError(A.RTR_ERR_INVALID, "librtr_hip.so ABI version mismatch")
     _LIB = L
     return L
+
+
+def test_lib():
+    """librtr_hip_test.so (include/rtr_hip_test.h): the device unit kernels the parity tests and tools/ drive.  Loaded on
+    first use; never needed to render."""
+    global _TEST_LIB
+    if _TEST_LIB is not None:
+        return _TEST_LIB
+    lib()  # the product library first: the test library links against it
+    path = os.environ.get("RTR_HIP_TEST_LIBRARY") or os.path.join(os.path.dirname(library_path()), "librtr_hip_test.so")
+    if not os.path.exists(path):
+        path = os.path.join(_HERE, "librtr_hip_test.so")
+    if not os.path.exists(path):
+        raise RtrError(A.RTR_ERR_DEVICE, "test library %s is missing: run __graft_entry__.build()" % path)
+    T = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    for name in ("rtr_test_hits", "rtr_test_materials", "rtr_test_lights"):
+        getattr(T, name).argtypes = [vp, vp, C.c_int64]
+    T.rtr_test_li.argtypes = [vp, C.POINTER(A.RenderParamsC), vp, C.c_int64]
+    T.rtr_test_reference_order.argtypes = [vp, C.c_int]
+    T.rtr_test_stream8.argtypes = [vp, C.c_int64, C.c_int]
+    T.rtr_test_sincos_exhaustive.argtypes = [vp, C.POINTER(C.c_uint64)]
+    T.rtr_test_issue_rates.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
+    T.rtr_test_shared_division.argtypes = [vp, C.POINTER(C.c_uint64)]
+    _TEST_LIB = T
+    return T
 
 
 def validate_scene(scene):
@@ -184,6 +203,16 @@ class Context:
         self._chk(self._L.rtr_li_samples(self._h, C.byref(params), ijs.ctypes.data, out.ctypes.data, len(ijs)))
         return out
 
+    def li_rays(self, params, origins, directions, times, rng_states):
+        """``Integrator::Li`` of arbitrary rays (n, 3) / (n, 3) / (n,) with the xorshift32 state (n,) the reference's
+        generator would hold on entry: radiance (n, 3)."""
+        n = len(origins)
+        rays = np.zeros(n, dtype=A.LI_RAY_DTYPE)
+        rays["origin"], rays["direction"], rays["time"], rays["rng_state"] = origins, directions, times, rng_states
+        out = np.zeros((n, 3), dtype=np.float64)
+        self._chk(self._L.rtr_li_rays(self._h, C.byref(params), rays.ctypes.data, out.ctypes.data, n))
+        return out
+
     def synchronize(self):
         self._chk(self._L.rtr_synchronize(self._h))
 
@@ -199,16 +228,16 @@ class Context:
 
     def reference_order(self, on):
         """Force the reference-order traversal for rtr_test_hits (renders use params.flags)."""
-        self._chk(self._L.rtr_test_reference_order(self._h, 1 if on else 0))
+        self._chk(test_lib().rtr_test_reference_order(self._h, 1 if on else 0))
 
     def stream8(self, n_doubles, repeat=1):
         """Counter calibration: stream n_doubles doubles in and out, 8 bytes per lane (include/rtr_hip_test.h)."""
-        self._chk(self._L.rtr_test_stream8(self._h, int(n_doubles), int(repeat)))
+        self._chk(test_lib().rtr_test_stream8(self._h, int(n_doubles), int(repeat)))
 
     def sincos_mismatches(self):
         """All 2^32 sampler angles: how many give sincos(phi) != (sin(phi), cos(phi)) in some bit (include/rtr_hip_test.h)."""
         n = C.c_uint64(0)
-        self._chk(self._L.rtr_test_sincos_exhaustive(self._h, C.byref(n)))
+        self._chk(test_lib().rtr_test_sincos_exhaustive(self._h, C.byref(n)))
         return int(n.value)
 
     ISSUE_CLASSES = ("v_fma_f64", "v_add_f64", "v_mul_f64", "v_rcp_f64", "v_rsq_f64", "v_cmp_lt_f64", "v_cndmask_b32",
@@ -217,19 +246,19 @@ class Context:
     def issue_rates(self):
         """Shader cycles per wave-instruction and class with four waves on every SIMD (include/rtr_hip_test.h)."""
         out = (C.c_double * len(self.ISSUE_CLASSES))()
-        self._chk(self._L.rtr_test_issue_rates(self._h, out, len(self.ISSUE_CLASSES)))
+        self._chk(test_lib().rtr_test_issue_rates(self._h, out, len(self.ISSUE_CLASSES)))
         return dict(zip(self.ISSUE_CLASSES, [float(x) for x in out]))
 
     def shared_division_mismatches(self):
         """2^32 operand pairs: how many quotients of the shared-reciprocal division differ from n / d (include/rtr_hip_test.h)."""
         n = C.c_uint64(0)
-        self._chk(self._L.rtr_test_shared_division(self._h, C.byref(n)))
+        self._chk(test_lib().rtr_test_shared_division(self._h, C.byref(n)))
         return int(n.value)
 
     # device unit kernels over golden-vector records (include/rtr_hip_test.h)
     def test_records(self, kind, recs, params=None):
         out = np.ascontiguousarray(recs.copy())
-        fn = getattr(self._L, "rtr_test_" + kind)
+        fn = getattr(test_lib(), "rtr_test_" + kind)
         if kind == "li":
             self._chk(fn(self._h, C.byref(params), out.ctypes.data, len(out)))
         else:

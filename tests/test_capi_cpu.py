@@ -14,17 +14,29 @@ rtr = G.rtr
 ROOT = G.ROOT
 
 
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(rtr_[a-z_0-9]+)\s*\(", text))
+
+
 def test_library_exports_every_declared_symbol():
+    """include/rtr_hip.h = the product (librtr_hip.so); include/rtr_hip_test.h = the device unit kernels of the parity
+    tests, a library of their own (librtr_hip_test.so).  Neither exports what the other declares."""
     lib = rtr.native.lib()
-    declared = set()
-    for h in ("rtr_hip.h", "rtr_hip_test.h"):
-        text = open(os.path.join(ROOT, "include", h)).read()
-        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        declared |= set(re.findall(r"\b(rtr_[a-z_0-9]+)\s*\(", text))
-    assert declared == set(rtr.native.EXPORTS)
-    for name in declared:
+    assert _declared("rtr_hip.h") == set(rtr.native.EXPORTS)
+    for name in rtr.native.EXPORTS:
         assert getattr(lib, name) is not None
     assert lib.rtr_abi_version() == A.RTR_ABI_VERSION
+    test_lib = rtr.native.test_lib()
+    assert _declared("rtr_hip_test.h") == set(rtr.native.TEST_EXPORTS)
+    for name in rtr.native.TEST_EXPORTS:
+        assert getattr(test_lib, name) is not None
+        assert not hasattr(lib, name), "%s: test hook in the product library" % name
+    # no test kernel is linked into the product
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", rtr.native.library_path()], stdout=subprocess.PIPE).stdout.decode()
+    assert "k_test_" not in syms and "k_stream8" not in syms
 
 
 def test_sample_seed_matches_oracle():

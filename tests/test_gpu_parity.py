@@ -198,6 +198,69 @@ def test_per_ray_entry_of_the_main_abi(ctx):
         ctx.li_samples(p, [[p.image_width, 0, 0]])
 
 
+def _camera_rays(sc, p, ijs):
+    """camera::get_ray (renderer/camera.h:32-40) of camera samples on the host, in the reference's operation order
+    (numpy float64 = IEEE binary64): origins, directions, times and the generator state after the ray was made."""
+    cam = sc.camera[0]
+    org, llc = np.array(cam["origin"], dtype=np.float64), np.array(cam["lower_left_corner"], dtype=np.float64)
+    hor, ver = np.array(cam["horizontal"], dtype=np.float64), np.array(cam["vertical"], dtype=np.float64)
+    cu, cv = np.array(cam["u"], dtype=np.float64), np.array(cam["v"], dtype=np.float64)
+    lens, t0, t1 = float(cam["lens_radius"]), float(cam["time0"]), float(cam["time1"])
+    lib = G.rtr.native.lib()
+    M = 0xFFFFFFFF
+
+    def nxt(state):
+        state ^= (state << 13) & M
+        state ^= state >> 17
+        state ^= (state << 5) & M
+        return state, np.float64(state) * np.float64(2.3283064365386963e-10)
+
+    o, d, tm, st = [], [], [], []
+    W, H = p.image_width, p.image_height
+    for i, j, s in ijs:
+        state = lib.rtr_sample_seed(p.seed, W, int(i), int(j), int(s))
+        state, r = nxt(state)
+        u = (np.float64(i) + r) / np.float64(W - 1)
+        state, r = nxt(state)
+        v = (np.float64(j) + r) / np.float64(H - 1)
+        while True:  # random_in_unit_disk (vec3.h:250-257): y takes the first draw
+            state, r = nxt(state)
+            y = np.float64(-1.0) + np.float64(2.0) * r
+            state, r = nxt(state)
+            x = np.float64(-1.0) + np.float64(2.0) * r
+            if x * x + y * y + np.float64(0.0) < 1:
+                break
+        rd = np.array([lens * x, lens * y, lens * np.float64(0.0)])
+        offset = rd[0] * cu + rd[1] * cv
+        direction = llc + u * hor + v * ver - org - offset
+        state, r = nxt(state)
+        o.append(org + offset), d.append(direction), tm.append(np.float64(t0) + (np.float64(t1) - np.float64(t0)) * r)
+        st.append(state)
+    return np.array(o), np.array(d), np.array(tm), np.array(st, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("name,sid,integ", [("li_scene21_i4.bin", 21, 4), ("li_scene07_i1.bin", 7, 1), ("li_scene09_i1.bin", 9, 1)])
+def test_arbitrary_ray_entry_of_the_main_abi(ctx, name, sid, integ):
+    """rtr_li_rays (include/rtr_hip.h): Integrator::Li takes ANY ray (renderer/integrator.h:12-19).  Fed the camera rays of
+    the reference's per-sample records -- made on the host, generator state after camera::get_ray included -- it must
+    return the records' radiance bit for bit (scene 9: media draw inside the casts, so the state matters all the way)."""
+    sc = _upload(ctx, sid)
+    info = G.MANIFEST["files"][name]
+    gold = G.records(name, A.LI_DTYPE)[:512]
+    p = A.make_params(info["info"]["width"], info["info"]["height"], info["spp"], integrator=integ, seed=info["seed"])
+    ijs = np.stack([gold["i"], gold["j"], gold["s"]], axis=1)
+    o, d, tm, st = _camera_rays(sc, p, ijs)
+    L = ctx.li_rays(p, o, d, tm, st)
+    same = ctx.li_samples(p, ijs)
+    assert np.array_equal(_bits(L), _bits(same)), "host-made camera rays differ from the device's"
+    if sid != 9:
+        assert np.array_equal(_bits(L), _bits(gold["L"]))
+    else:  # OCML log / sin vs glibc: the recorded residue of test_li_records applies
+        assert np.allclose(L, gold["L"], rtol=1e-9, atol=1e-12)
+    with pytest.raises(G.rtr.RtrError):
+        ctx.li_rays(p, o[:1], d[:1], tm[:1], np.zeros(1, dtype=np.uint32))
+
+
 IMG_CASES = ["img_scene07_i1_64_spp16.f64", "img_scene07_i4_64_spp16.f64", "img_scene21_i4_64_spp16.f64",
              "img_scene23_i4_64_spp16.f64", "img_scene09_i1_64_spp16.f64", "img_scene22_i4_64_spp16.f64",
              "img_scene21_i4_128_spp32.f64", "img_scene01_i1_64_spp16.f64", "img_scene08_i1_64_spp16.f64",
