@@ -20,17 +20,19 @@ with scene and framebuffer resident in HBM.  At N = 1 the same run also
     used, and compares it with the CPU oracle on the same seeds (`parity`);
   * times the reference's own tile-threaded renderer on the host cores (`cpu_baseline`).
 
-`roofline`: the megakernel keeps path state in registers and LDS, so its binding limit is FP64
-vector issue, not HBM (profiles/: 0.06 % of the algorithmic bytes reach memory).  `bound` is
-"fp64_valu": achieved = (wave-level VALU instructions of the render, from the committed rocprofv3
-SQ pass in profiles/*_counts.json, scaled to this run's sample count) x 64 lanes x lane utilisation
-x 2 flop / HIP-event kernel time, against the 78.6 TFLOP/s FP64 vector peak (= 16 lanes/clk on
-1024 SIMDs at 2.4 GHz, FMA = 2 flop: every instruction is priced as an FP64 FMA slot).  The figure
-SURVEY 8(d) prescribes -- algorithmic state bytes of a wavefront tracer (172 B/sample + 280
-B/closest segment + 168 B/shadow segment) over the same time against 8 TB/s -- is kept as
-`hbm_equivalent`; it is the binding roofline only when the wavefront pipeline ran, and then
-`bound` says "hbm".  `traffic` = HBM bytes of one render from separate FETCH_SIZE / WRITE_SIZE
-passes (same file).
+`roofline`: the megakernel keeps path state in registers and LDS, so its binding limit is not HBM
+(profiles/: 0.06 % of the algorithmic bytes reach memory) but the vector unit.  `bound` is "fp64_valu" and
+`frac` = COUNTED FP64 flop / 78.6 TFLOP/s: the SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 class counters of the
+committed rocprofv3 pass (profiles/rNN_counts.json, scaled to this run's sample count; fma = 2 flop) x 64 lanes x
+lane utilisation / the HIP-event kernel time.  Beside it `issue` says how full the SIMDs' instruction issue was:
+every counted instruction class priced with its MEASURED cost (profiles/rNN_issue_rates.json, tools/issue_rates.py:
+cycles per SIMD and wave-instruction with four waves resident -- FP64 add / mul / fma / compare 2.8, v_rcp / v_rsq
+f64 10.2, 32-bit VALU 1.7, scalar ALU 2.8) against SIMDs x clock x time.  The counter file carries a hash of the
+sources it was measured on; `stale` is true when the library that ran is built from other sources.  The figure
+SURVEY 8(d) prescribes -- algorithmic state bytes of a wavefront tracer (172 B/sample + 280 B/closest segment +
+168 B/shadow segment) over the same time against 8 TB/s -- is kept as `hbm_equivalent`; it is the binding roofline
+only when the wavefront pipeline ran, and then `bound` says "hbm".  `traffic` = HBM bytes of one render from
+separate FETCH_SIZE / WRITE_SIZE passes (same file).
 """
 import argparse
 import glob
@@ -82,6 +84,25 @@ def load_scene(pkg, scene_id):
             return pkg.Scene.from_bytes(f.read())
 
 
+ISSUE_COSTS = {}
+LIB_HASH = None
+
+
+def load_issue_costs():
+    """Newest profiles/rNN_issue_rates.json (tools/issue_rates.py): cycles a wave spends per instruction with four waves
+    on a SIMD, folded to cycles per SIMD."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_issue_rates.json")))
+    if not files:
+        return {}
+    with open(files[-1]) as f:
+        w = json.load(f)["cycles_per_wave_instruction_at_4_waves_per_simd"]
+    return {"file": "profiles/" + os.path.basename(files[-1]),
+            "cycles_per_simd": {"f64_arith": round((w["v_fma_f64"] + w["v_add_f64"] + w["v_mul_f64"]) / 12, 3),
+                                "f64_trans": round((w["v_rcp_f64"] + w["v_rsq_f64"]) / 8, 3),
+                                "valu_32bit": round((w["v_mov_b32"] + w["v_fma_f32"]) / 8, 3),
+                                "salu": round(w["s_and_b64"] / 4, 3)}}
+
+
 def committed_counts():
     """Newest profiles/rNN_counts.json: per workload, the rocprofv3 counter sums of ONE render."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_counts.json")))
@@ -127,8 +148,10 @@ def cpu_baseline(pkg, scene, name, wl):
                       (wl["scene"], wl["integ"], W, H, spp, sec)}
 
 
-def crop_parity(pkg, ctx, scene, wl, chunks_used, pipeline):
-    """64x64 crop of the full-size image at the FULL spp against the CPU oracle on the same seeds."""
+def crop_parity(pkg, ctx, scene, wl, chunks_used, pipeline, timed_image=None, timed_mask=None):
+    """64x64 crop of the full-size image at the FULL spp against the CPU oracle on the same seeds.  `timed_image`: the
+    framebuffer the TIMED steps wrote (gathered on rank 0): its crop is compared too, so the check covers the very
+    summation that was timed (its chunking differs from a crop render's: other tile count)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _golden as G  # the checker (test infrastructure)
@@ -152,12 +175,22 @@ def crop_parity(pkg, ctx, scene, wl, chunks_used, pipeline):
            "rmse_gamma_vs_oracle": float(np.sqrt(np.mean((np.clip(np.sqrt(timed), 0, 1) -
                                                           np.clip(np.sqrt(ref), 0, 1)) ** 2))),
            "seconds": round(time.time() - t0, 2)}
+    if timed_image is not None:
+        crop = timed_image[y0:y0 + 64, x0:x0 + 64]
+        m = np.ones((64, 64), dtype=bool) if timed_mask is None else timed_mask[y0:y0 + 64, x0:x0 + 64]
+        out["timed_framebuffer_pixels_compared"] = int(m.sum())
+        out["rel_l2_timed_framebuffer_vs_oracle"] = G.rel_l2(crop[m], ref[m]) if m.any() else None
     no_libm = wl["scene"] in (7, 21)  # + - * / sqrt only on these paths: the device must match bit for bit
     out["bar"] = "bit-exact (chunks=1), rel-L2 <= 1e-13 chunked" if no_libm else "rel-L2 <= 1e-3"
     out["ok"] = bool(out["bit_exact_chunks1"] and out["rel_l2_vs_oracle"] <= 1e-13) if no_libm \
         else bool(out["rel_l2_vs_oracle"] <= 1e-3 and out["rel_l2_chunks1_vs_oracle"] <= 1e-3)
-    for k in ("rel_l2_vs_oracle", "rel_l2_chunks1_vs_oracle", "rel_l2_chunked_vs_chunks1", "rmse_gamma_vs_oracle"):
-        out[k] = float("%.3e" % out[k])
+    timed = out.get("rel_l2_timed_framebuffer_vs_oracle")
+    if timed is not None:
+        out["ok"] = bool(out["ok"] and timed <= (1e-13 if no_libm else 1e-3))
+    for k in ("rel_l2_vs_oracle", "rel_l2_chunks1_vs_oracle", "rel_l2_chunked_vs_chunks1", "rmse_gamma_vs_oracle",
+              "rel_l2_timed_framebuffer_vs_oracle"):
+        if out.get(k) is not None:
+            out[k] = float("%.3e" % out[k])
     return out
 
 
@@ -186,17 +219,37 @@ def roofline(name, pipe_name, counts, samples, closest, shadow, kernel_ms, n_gpu
         return r
     insts = c["insts_valu"] * per / n_gpus          # wave-level VALU instructions of this GPU's share
     lane_util = c["thread_cycles_valu"] / c["insts_valu"] / 64.0
-    tflops = insts * 64 * lane_util * 2 / t * 1e-12  # every active lane-slot priced as one FP64 FMA
+    f64 = c.get("f64") or {}
+    # the roofline proper: FP64 flop the class counters saw (add / mul / transcendental 1, fma 2 per active lane)
+    flop = (c.get("f64_flop") or 0.0) * per / n_gpus * 64 * lane_util
+    tflops = flop / t * 1e-12
     r = {"bound": "fp64_valu", "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic, "kernel_ms": round(kernel_ms, 3),
+         "achieved_is": "counted FP64 flop (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes x lane utilisation) / kernel time",
          "valu_insts_per_sample": round(c["insts_valu"] / c["samples"], 1), "lane_utilisation": round(lane_util, 4),
-         # share of the chip's VALU issue slots (4 clk per wave64 FP64-rate instruction) that held an instruction
-         "issue_frac": round(insts * 4 / (1024 * 2.4e9 * t), 4),
          "hbm_equivalent": eq}
     if traffic is not None:
         r["hbm_actual_GBs"] = round(traffic / t * 1e-9, 2)
-    if c.get("f64_flop") is not None:  # class counters (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64), when the box has them
-        r["fp64_flop_counted_TFLOPs"] = round(c["f64_flop"] * per / n_gpus * 64 * lane_util / t * 1e-12, 3)
+    # how full the SIMDs' instruction issue was: each class at its measured cost (cycles per SIMD and wave-instruction)
+    costs = ISSUE_COSTS.get("cycles_per_simd") or {}
+    if f64 and costs:
+        arith = (f64["add"] + f64["mul"] + f64["fma"]) * per / n_gpus
+        trans = f64["trans"] * per / n_gpus
+        other = max(insts - arith - trans, 0.0)            # compares, selects, moves, integer, conversions
+        salu = (f64.get("salu", 0.0) + f64.get("smem", 0.0)) * per / n_gpus
+        clock = c.get("clock_ghz") or 2.4
+        avail = 1024 * clock * 1e9 * t                       # SIMD cycles of the kernel
+        need_lo = arith * costs["f64_arith"] + trans * costs["f64_trans"] + other * costs["valu_32bit"] + salu * costs["salu"]
+        need_hi = need_lo + other * (costs["f64_arith"] - costs["valu_32bit"])  # every "other" VALU an FP64 compare
+        r["issue"] = {"valu_f64_arith": round(arith), "valu_f64_transcendental": round(trans), "valu_other": round(other),
+                      "scalar": round(salu), "costs_cycles_per_simd": costs, "costs_file": ISSUE_COSTS.get("file"),
+                      "clock_ghz": clock, "clock_is": "GRBM_GUI_ACTIVE / 8 / kernel time of the counter pass" if c.get("clock_ghz") else "assumed",
+                      "utilisation": [round(need_lo / avail, 4), round(need_hi / avail, 4)],
+                      "utilisation_is": "SIMD cycles the counted instructions need at their measured issue costs / SIMDs x clock "
+                                        "x time; [other VALU priced as 32-bit moves, as FP64 compares]"}
+    r["counts_source_hash"] = c.get("source_hash") or counts.get("_source_hash")
+    r["library_source_hash"] = LIB_HASH
+    r["stale"] = bool(r["counts_source_hash"] != LIB_HASH)
     return r
 
 
@@ -249,6 +302,9 @@ def main():
 
     pipeline = {"auto": A.PIPELINE_AUTO, "mega": A.PIPELINE_MEGAKERNEL, "wavefront": A.PIPELINE_WAVEFRONT}[args.pipeline]
     counts, counts_file = committed_counts()
+    global ISSUE_COSTS, LIB_HASH
+    ISSUE_COSTS = load_issue_costs()
+    LIB_HASH = pkg.build.source_hash()
     ctx = pkg.Context(local_rank)
     stream = torch.cuda.Stream()  # a real (non-null) hipStream_t the library launches on; events use it too
     ctx.set_stream(stream.cuda_stream)
@@ -341,7 +397,7 @@ def main():
             "image_mean": round(mean, 6),
         }
         if with_parity:
-            line["parity"] = crop_parity(pkg, ctx, scene, wl, st["spp_chunks"], pipeline)
+            line["parity"] = crop_parity(pkg, ctx, scene, wl, st["spp_chunks"], pipeline, image, px_mask)
         if with_cpu:
             line["cpu_baseline"] = cpu_baseline(pkg, scene, name, wl)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 2)

@@ -223,7 +223,11 @@ typedef struct rtr_render_params {
     int32_t tile_stride;
     /* The spp samples of a pixel may be summed as `spp_chunks` consecutive partial sums that
      * are then added in order (more parallelism on small images).  1 = one running sum in
-     * sample order, exactly like renderer.h:72-79; 0 = let the library choose. */
+     * sample order, exactly like renderer.h:72-79; 0 = let the library choose.  The library's choice depends on
+     * the GPU, on the scene's kernel variant and on how many tiles the call owns, so with 0 the same image rendered
+     * as ONE call, or tile-sharded over N contexts, or on another device agrees within 1e-13 relative (another
+     * summation order) but not bit for bit; with 1, or any explicit count, every pixel is the same bits under every
+     * sharding (tests: test_sharded_render_equals_unsharded). */
     int32_t spp_chunks;
     int32_t flags; /* RTR_FLAG_* */
 } rtr_render_params;

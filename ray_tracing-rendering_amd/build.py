@@ -29,6 +29,21 @@ def _sources(d, exts):
     return out + [os.path.join(INC, f) for f in os.listdir(INC)]
 
 
+def source_hash():
+    """sha256 over what librtr_hip.so is built from (csrc/, include/, the compile flags): ties a committed counter file
+    (profiles/rNN_counts.json) to the library it was measured on -- bench.py marks its roofline stale when they differ."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (CSRC, INC):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".h", ".hip")) and not name.startswith(("rtr_test", "rt_test")):
+                h.update(name.encode())
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(f.read())
+    h.update(" ".join(HIP_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 

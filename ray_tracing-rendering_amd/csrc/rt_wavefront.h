@@ -737,7 +737,16 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
     const int batch = 8;
     int par = 0, iter = 0, n_batches = 0;
     bool cancelled = false;
+    /* every iteration advances every live slot by one path segment: a slot holds at most ceil(spp / chunks) samples
+     * of at most max_depth segments (+ one iteration each to start the next sample) -- more iterations than that mean a
+     * slot that never finishes (a bug in the live-block accounting, a NaN in the path state), not work */
+    const long long iter_bound = ((long long)P.spp / P.chunks + 1) * ((long long)P.max_depth + 2) + 4 * batch;
     for (;;) {
+        if (iter > iter_bound) {
+            (void)hipStreamSynchronize(stream);
+            err = "wavefront pipeline: live blocks left after the largest possible number of iterations";
+            return RTR_ERR_DEVICE;
+        }
         for (int b = 0; b < batch; ++b, ++iter) {
 #define WF_EXTEND_LS(T)                                                                                      \
     do {                                                                                                     \

@@ -57,6 +57,7 @@ struct rtr_context {
     WavefrontPool pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stats_pending = false;
+    bool in_flight = false; /* stream-ordered work of a render call is queued whose statistics are not pending (an error return) */
     rtr_render_stats stats{};
     /* Cancel.  Renders are numbered; rtr_cancel() covers every render issued so far: it stores the newest
      * id in `cancelled_upto` and in the device word the kernels poll.  A render issued afterwards carries a
@@ -490,7 +491,13 @@ int choose_chunks(rtr_context* c, RenderK P, int integrator, int pipeline, int t
 }
 
 int finish_stats(rtr_context* c) {
-    if (!c->stats_pending) return RTR_OK;
+    if (!c->stats_pending) {
+        if (c->in_flight) { /* a call that failed after its first stream-ordered step: wait for what it queued */
+            c->in_flight = false;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        return RTR_OK;
+    }
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -523,6 +530,7 @@ int finish_stats(rtr_context* c) {
     c->stats.device_ms = ms;
     if (h[7]) c->stats.cancelled = 1; /* workgroups that saw the cancel before their last sample */
     c->stats_pending = false;
+    c->in_flight = false;
     return RTR_OK;
 }
 
@@ -942,8 +950,8 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     const size_t partial_bytes = (size_t)P.n_tiles * chunks * 3 * RTR_BLOCK * sizeof(double);
     const size_t done_bytes = (size_t)P.n_tiles * chunks * sizeof(int);
     const bool same_tiles = tiles == c->last_tiles;
-    if (c->stats_pending && (!same_tiles || partial_bytes > c->b_partial.cap || done_bytes > c->b_done.cap ||
-                             pipeline == RTR_PIPELINE_WAVEFRONT)) {
+    if ((c->stats_pending || c->in_flight) && (!same_tiles || partial_bytes > c->b_partial.cap || done_bytes > c->b_done.cap ||
+                                               pipeline == RTR_PIPELINE_WAVEFRONT)) {
         if ((rc = finish_stats(c))) return rc;
     }
     /* everything that can fail comes before the first stream-ordered side effect, so an error return leaves
@@ -965,6 +973,9 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
     const uint32_t id = c->render_seq.fetch_add(1) + 1; /* rtr_cancel() from now on covers this render */
     P.render_id = id;
     c->stats_pending = false; /* an unfinished earlier render's statistics are dropped here */
+    c->in_flight = true;      /* ... but what it queued, and what this call queues from here on, is still tracked: an error
+                                 return below leaves it set, and the next call (or rtr_get_stats) waits before it touches
+                                 the tile list, the workspace or the wavefront pool */
     c->stats = rtr_render_stats{};
     c->stats.spp_chunks = chunks;
     c->pending_id = id;

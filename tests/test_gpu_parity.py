@@ -439,8 +439,9 @@ def test_next_integrators(ctx, sid, integ, img_name):
                (out["n_shadow"] == gold["n_shadow"])
         if sid in (7, 21):
             assert same.all()
-        else:
-            assert same.mean() >= 0.995
+        else:  # OCML vs glibc ulps: the measured number of samples that took another path
+            G.residue("next_integrators.scene%02d.i%d.flags%d.paths_differ" % (sid, integ, flags), int((~same).sum()),
+                      int(0.005 * same.size))
         if (sid, integ) == (21, 3):
             assert np.array_equal(_bits(out["L"]), _bits(gold["L"]))
         else:
@@ -470,7 +471,9 @@ def test_delta_and_environment_lights(ctx, sid):
         assert np.array_equal(out["pdf"] == 0, gold["pdf"] == 0)
         for f in ("Li", "pdf", "pdf_dir"):  # an ulp in (u,v) can select the neighbouring texel: rare
             same_nan = np.isnan(out[f]) & np.isnan(gold[f])  # pdf() of the zero direction of a failed sample
-            assert (_close(out[f], gold[f], 1e-9) | same_nan).mean() >= 0.99, f
+            ok = _close(out[f], gold[f], 1e-9) | same_nan
+            G.residue("lights_scene%02d.%s.records_outside_1e-9" % (sid, f), int((~ok.reshape(len(ok), -1).all(axis=1)).sum()),
+                      int(0.01 * len(ok)))
         assert np.abs(out["wi"] - gold["wi"]).max() <= 1e-12
         assert np.all(np.isinf(out["dist"]))
     else:
@@ -489,7 +492,7 @@ def test_delta_and_environment_lights(ctx, sid):
         # (the harness files a directional light's shadow rays, t_max = inf, under "closest")
         same = (o["rng_exit"] == grec["rng_exit"]) & \
                (o["n_closest"] + o["n_shadow"] == grec["n_closest"] + grec["n_shadow"])
-        assert same.mean() >= 0.995
+        G.residue("lights_scene%02d.i%d.paths_differ" % (sid, integ), int((~same).sum()), int(0.005 * same.size))
         assert np.all(_close(o["L"][same], grec["L"][same], 1e-9).all(axis=1))
         img, iinfo = G.image(img_name)
         for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
@@ -647,7 +650,8 @@ def test_other_integrators_on_every_scene(ctx, sid):
             if out is None:
                 continue
             close = np.all(_close(out, ora, 1e-9) | (np.abs(out - ora) <= 1e-12), axis=-1)
-            assert close.mean() >= 0.985, (integ, pipe, close.mean())
+            G.residue("other_integrators.scene%02d.i%d.pipe%d.pixels_outside_1e-9" % (sid, integ, pipe), int((~close).sum()),
+                      int(0.015 * close.size))
             assert G.rel_l2(out, ora) <= 5e-2 or np.abs(out - ora).max() <= 1e-12, (integ, pipe)
 
 
@@ -671,10 +675,10 @@ def test_image_texture(ctx):
     p = A.make_params(info["info"]["width"], info["info"]["height"], info["spp"], integrator=1, seed=info["seed"])
     o = ctx.test_records("li", grec, params=p)
     same = o["rng_exit"] == grec["rng_exit"]
-    assert same.mean() >= 0.995
-    # an ulp of difference in (u,v) can select a neighbouring texel: allow a few samples to differ
+    G.residue("image_texture.scene04.i1.paths_differ", int((~same).sum()), int(0.005 * same.size))
+    # an ulp of difference in (u,v) can select a neighbouring texel: the measured number of samples that differ
     ok = np.all(_close(o["L"][same], grec["L"][same], 1e-9), axis=1)
-    assert ok.mean() >= 0.99
+    G.residue("image_texture.scene04.i1.samples_outside_1e-9", int((~ok).sum()), int(0.01 * ok.size))
     img, iinfo = G.image("img_scene04_i1_64_spp16.f64")
     for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
         q = A.make_params(iinfo["width"], iinfo["height"], iinfo["spp"], integrator=1, seed=iinfo["seed"],
@@ -745,25 +749,57 @@ def test_cancel_covers_queued_renders_only(ctx, rtr):
     assert not ctx.stats()["cancelled"]
 
 
-@pytest.mark.parametrize("workload", ["cornell_mis", "cornell_literal", "final_rr", "final_mis", "mis_spheres"])
+@pytest.mark.parametrize("workload", ["cornell_mis", "cornell_literal", "final_rr", "final_mis", "mis_spheres", "c5_shard"])
 def test_full_spp_crop_of_every_baseline_config(ctx, rtr, workload):
     """What is timed and shipped (spp_chunks = 0: the library's own partial sums) against the oracle at the
-    configuration's REAL spp: a 64x64 crop of the full-size image, partial sums chosen by the library (spp_chunks = 0).
-    Scenes 07 / 21 (no libm on the path): bit-exact with one running sum, <= 1e-13 with partial sums; the others
-    within the 1e-3 tolerance of BASELINE.json (measured: <= 1e-12).  Same check bench.py prints as `parity`."""
+    configuration's REAL spp.  (1) The megakernel renders the configuration at FULL size exactly as bench.py times it
+    (c5_shard: the tiles one rank of eight owns) and the 64x64 centre crop of THAT framebuffer -- the summation that is
+    timed -- is compared with the oracle; (2) the crop rendered on its own (another tile count, so other partial sums),
+    both pipelines.  Scenes 07 / 21 (no libm on the path): bit-exact with one running sum, <= 1e-13 with partial sums;
+    the others within the 1e-3 tolerance of BASELINE.json (measured: <= 1e-12).  Same check bench.py prints as `parity`."""
     import bench
+    import torch
     wl = dict(bench.WORKLOADS[workload])
     sc = bench.load_scene(rtr, wl["scene"])
     ctx.upload(sc)
+    W, H, stride = wl["W"], wl["H"], wl.get("stride", 1)
+    full = A.make_params(W, H, wl["spp"], integrator=wl["integ"], seed=1, spp_chunks=0, tile_first=0, tile_stride=stride)
+    fb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    ctx.render_into(full, fb.data_ptr(), W, blocking=True)
+    timed_chunks = ctx.stats()["spp_chunks"]
+    image = fb.cpu().numpy()
+    del fb
+    mask = G.rtr.renderer.ownership_mask(W, H, 0, stride)
     for pipe in (A.PIPELINE_MEGAKERNEL, A.PIPELINE_WAVEFRONT):
-        probe = A.make_params(wl["W"], wl["H"], wl["spp"], integrator=wl["integ"], seed=1, spp_chunks=0, pipeline=pipe,
-                              region=(0, 0, wl["W"], wl["H"]))
-        chunks = ctx.plan_chunks(probe)
-        res = bench.crop_parity(rtr, ctx, sc, wl, chunks, pipe)
+        timed = pipe == A.PIPELINE_MEGAKERNEL
+        res = bench.crop_parity(rtr, ctx, sc, wl, timed_chunks, pipe, image if timed else None, mask if timed else None)
         print(workload, pipe, res)
         assert res["ok"], res
         assert res["rel_l2_chunked_vs_chunks1"] <= 1e-13
         G.residue("crop.%s.pipe%d.rel_l2_vs_oracle" % (workload, pipe), res["rel_l2_vs_oracle"], 1e-3)
+        if timed:
+            assert res["timed_framebuffer_pixels_compared"] > 0
+            G.residue("crop.%s.timed_framebuffer.rel_l2_vs_oracle" % workload, res["rel_l2_timed_framebuffer_vs_oracle"], 1e-3)
+
+
+def test_sharded_render_equals_unsharded(ctx, rtr):
+    """Tile sharding on the device: two contexts on GPU 0 render the tiles index % 2 == 0 / 1 of scene 21; their union
+    against the unsharded image.  With one running sum per pixel (spp_chunks = 1) every pixel is the same bits for any
+    sharding; with the library's own partial sums (spp_chunks = 0) the number of sums depends on how many tiles a call
+    owns, so the union agrees within 1e-13 -- rounding of another summation order, documented in include/rtr_hip.h."""
+    sc = _upload(ctx, 21)
+    W, H, spp = 160, 128, 64
+    with rtr.Context(0) as other:
+        other.upload(sc)
+        for chunks in (1, 0):
+            whole = ctx.render(A.make_params(W, H, spp, integrator=4, seed=9, spp_chunks=chunks))
+            union = np.zeros_like(whole)
+            for rank, c in enumerate((ctx, other)):
+                c.render(A.make_params(W, H, spp, integrator=4, seed=9, spp_chunks=chunks, tile_first=rank, tile_stride=2), out=union)
+            if chunks == 1:
+                assert np.array_equal(_bits(union), _bits(whole))
+            else:
+                assert G.rel_l2(union, whole) <= 1e-13
 
 
 @pytest.mark.parametrize("sid,integ", [(21, 4), (9, 1), (22, 4), (22, 3), (1, 1), (23, 4), (8, 1)])

@@ -52,7 +52,14 @@ for cn in ("FETCH_SIZE", "WRITE_SIZE"):
         tot = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_stream8" in r["Kernel_Name"] and r["Counter_Name"] == cn)
         calib[cn] = {"counter_bytes": tot * 1024, "true_bytes": 4 * (1 << 30), "true_over_counter": 4 * (1 << 30) / (tot * 1024) if tot else None}
 passes = {}
-for p in ("sq", "f64", "f32", "fetch", "write"):
+# per-dispatch megakernel durations of the once-per-workload trace (kernel_trace_once.csv), in launch order
+kernel_ns = {}
+kt = os.path.join(out, "kernel_trace_once.csv")
+if os.path.exists(kt):
+    rows = sorted((r for r in csv.DictReader(open(kt)) if "k_mega" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    for i, r in enumerate(rows):
+        kernel_ns[i] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+for p in ("sq", "f64", "f32", "fetch", "write", "grbm"):
     f = os.path.join(out, "pmc_%s.csv" % p)
     if os.path.exists(f):
         passes[p] = renders(f)
@@ -76,6 +83,9 @@ for i, name in enumerate(workloads):
         # flop per wave-level instruction and lane: add / mul / transcendental 1, fma 2
         c["f64_flop"] = f["SQ_INSTS_VALU_ADD_F64"] + f["SQ_INSTS_VALU_MUL_F64"] + f["SQ_INSTS_VALU_TRANS_F64"] + \
             2 * f["SQ_INSTS_VALU_FMA_F64"]
+    if "grbm" in passes and kernel_ns.get(i):
+        # effective shader clock of the counter pass: GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+        c["clock_ghz"] = round(passes["grbm"][i]["c"]["GRBM_GUI_ACTIVE"] / 8.0 / kernel_ns[i], 3)
     if "f32" in passes:
         f = passes["f32"][i]["c"]
         c["f32"] = {k.replace("SQ_INSTS_VALU_", "").replace("SQ_", "").lower(): v for k, v in f.items()}
@@ -116,6 +126,10 @@ for w in ("cornell_mis", "final_rr"):
     counts.setdefault(w, {})["wavefront"] = c
 if calib:
     counts["_calibration_8B_per_lane"] = calib
+# what the counters were measured on: bench.py compares this with the library it runs (roofline.stale)
+import importlib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+counts["_source_hash"] = importlib.import_module("ray_tracing-rendering_amd.build").source_hash()
 json.dump(counts, open(os.path.join(out, "%s_counts.json" % tag), "w"), indent=1, sort_keys=True)
 with open(os.path.join(out, "%s_counts.txt" % tag), "w") as f:
     for cn, v in calib.items():

@@ -34,6 +34,7 @@ pass() { # name, counters...
 pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
 pass f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SALU SQ_INSTS_SMEM
 pass f32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA || true
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 # 4. the wavefront pipeline on the headline and on scene 9: kernel trace, SQ, FETCH, WRITE
@@ -55,4 +56,5 @@ for cn in FETCH_SIZE WRITE_SIZE; do
   cp $(find /tmp/cal -name '*counter_collection.csv' | head -1) $out/calib_$cn.csv
 done
 echo "calibration done"
+cd $root && python3 tools/issue_rates.py > $out/issue_rates.txt 2>&1 && cp gpurun_out/issue_rates.json $out/${tag}_issue_rates.json
 python3 $root/tools/pmc_counts.py $out $tag $wl
