@@ -297,6 +297,17 @@ int rtr_render_device(rtr_context* ctx, const rtr_render_params* params,
 int rtr_render_host(rtr_context* ctx, const rtr_render_params* params,
                     double* h_rgb, int64_t row_stride);
 
+/* Like rtr_render_host, but only what the call OWNS crosses PCIe: the tiles with index % tile_stride == tile_first that
+ * intersect the region, packed.  On return *n_tiles tiles were rendered; tile k is the reference's tile (*tile_ids)[k]
+ * (dispatch numbering, renderer.h:61-62) and occupies (*tiles)[k * 768 ...]: 16 rows of 16 pixels of 3 doubles, lowest
+ * row first, linear mean radiance (pixels of a border tile outside the image or region are undefined);
+ * (*tile_done)[k] = 1 when the tile was finished, 0 when a cancel came first (the reference's workers leave such a
+ * tile untouched, renderer.h:52-59).  The three arrays live in pinned host memory owned by the context and stay valid
+ * until its next render call.  Blocking.  This is what one worker of an N-GPU renderer calls: nothing is uploaded,
+ * one D2H copy of n_tiles x 6 KiB. */
+int rtr_render_tiles_host(rtr_context* ctx, const rtr_render_params* params, const double** tiles, const int32_t** tile_ids,
+                          const uint8_t** tile_done, int64_t* n_tiles);
+
 /* The number of partial sums per pixel the library would use for `params` (params->spp_chunks, or its own
  * choice for 0: depends on the scene's kernel variant, the pipeline and the number of owned tiles).  Returns
  * the count (>= 1) or a negative status.  Lets a caller render a crop with the summation of a full-size render. */

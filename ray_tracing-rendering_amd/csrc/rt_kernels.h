@@ -311,9 +311,11 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_resolve(const ResolveK R) {
     int i, j;
     bool active;
     tile_pixel(P, blockIdx.x, threadIdx.x, i, j, active);
-    if (!active) return;
     for (int c = 0; c < P.chunks; ++c) /* wave-uniform: scalar loads */
         if (!P.done[blockIdx.x * P.chunks + c]) return;
+    const bool packed = R.row_stride < 0;
+    if (packed && threadIdx.x == 0) R.tile_done[blockIdx.x] = 1;
+    if (!active) return;
     const double* in = P.partial + (size_t)blockIdx.x * P.chunks * 3 * RTR_BLOCK + threadIdx.x;
     double r = 0, g = 0, b = 0;
     for (int c = 0; c < P.chunks; ++c) {
@@ -325,7 +327,8 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_resolve(const ResolveK R) {
         in += 3 * RTR_BLOCK;
     }
     const double scale = 1.0 / P.spp; /* renderer.h:131 */
-    double* o = R.out + ((long long)(j - P.y0) * R.row_stride + (i - P.x0)) * 3;
+    double* o = packed ? R.out + ((long long)blockIdx.x * RTR_BLOCK + threadIdx.x) * 3
+                       : R.out + ((long long)(j - P.y0) * R.row_stride + (i - P.x0)) * 3;
     o[0] = scale * r;
     o[1] = scale * g;
     o[2] = scale * b;

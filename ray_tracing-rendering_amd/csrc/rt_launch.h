@@ -45,5 +45,6 @@ struct WavefrontPlan {
     size_t lds; /* traversal stack of the extend / connect stages */
 };
 int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan& plan, const RenderK& P, int integrator,
-                     double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<uint32_t>* cancelled_upto,
+                     double* d_rgb, int64_t row_stride, unsigned char* tile_done, hipStream_t stream,
+                     std::atomic<uint32_t>* cancelled_upto,
                      int* launches, std::string& err);

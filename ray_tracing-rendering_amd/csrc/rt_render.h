@@ -75,6 +75,8 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
 struct ResolveK {
     RenderK r;
     double* out; /* linear mean radiance, 3 doubles per pixel */
-    long long row_stride;
+    long long row_stride; /* pixels per row of `out`; < 0: `out` is PACKED -- owned tile k of the call at out[k * 768 ...]
+                             as 16 rows (lowest y first) of 16 pixels, and tile_done[k] = 1 once its sums are stored */
+    unsigned char* tile_done;
 };
 

@@ -670,8 +670,8 @@ inline int wf_lds_attr(K kernel, size_t bytes, std::string& err) {
  * the GPU and returns once the published number of live blocks is zero (everything it enqueued past that
  * point finds empty lists); it does not wait for the stream to drain. */
 int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan& plan, const RenderK& Pin, int integrator,
-                     double* d_rgb, int64_t row_stride, hipStream_t stream, std::atomic<uint32_t>* cancelled_upto,
-                     int* launches, std::string& err) {
+                     double* d_rgb, int64_t row_stride, unsigned char* tile_done, hipStream_t stream,
+                     std::atomic<uint32_t>* cancelled_upto, int* launches, std::string& err) {
     RenderK P = Pin;
     const long long n_slots_ll = (long long)P.n_tiles * P.chunks * RTR_BLOCK;
     if (n_slots_ll > (1ll << 30)) return wf_fail(err, RTR_ERR_UNSUPPORTED, "path pool larger than 2^30 slots");
@@ -830,7 +830,7 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
 #endif
     if (launches) *launches = n_launch;
     if (cancelled) return RTR_ERR_CANCELLED; /* unfinished pixels have no sum yet: the caller's buffer stays untouched */
-    ResolveK R{P, d_rgb, (long long)row_stride};
+    ResolveK R{P, d_rgb, (long long)row_stride, tile_done};
     rtr_launch_resolve(R, stream);
     ++n_launch;
     WF_HIP(hipGetLastError());

@@ -55,6 +55,8 @@ struct rtr_context {
     DevBuf b_tiles, b_partial, b_done, b_stats, b_cancel, b_test, b_stage;
     std::vector<int> last_tiles; /* what b_tiles holds */
     WavefrontPool pool;
+    void* h_stage = nullptr; /* pinned: rtr_render_tiles_host */
+    size_t h_stage_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stats_pending = false;
     bool in_flight = false; /* stream-ordered work of a render call is queued whose statistics are not pending (an error return) */
@@ -628,6 +630,7 @@ void rtr_destroy(rtr_context* c) {
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
+    if (c->h_stage) hipHostFree(c->h_stage);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -908,11 +911,20 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     return RTR_OK;
 }
 
+/* the render call proper; tile_done != nullptr: packed output (see ResolveK) */
+static int render_core(rtr_context* c, const rtr_render_params* p, double* d_rgb, int64_t row_stride, unsigned char* tile_done,
+                       int blocking);
+
 int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb, int64_t row_stride, int blocking) {
     if (!c) return RTR_ERR_INVALID;
     if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_render before rtr_upload_scene");
     if (int prc = params_check(c, p)) return prc;
     if (!d_rgb || row_stride < (int64_t)(p->x1 - p->x0)) return fail(c, RTR_ERR_INVALID, "bad output buffer / stride");
+    return render_core(c, p, d_rgb, row_stride, nullptr, blocking);
+}
+
+static int render_core(rtr_context* c, const rtr_render_params* p, double* d_rgb, int64_t row_stride, unsigned char* tile_done,
+                       int blocking) {
     HIPCHK(c, hipSetDevice(c->device));
     (void)hipGetLastError(); /* a launch error of an earlier call (ours or the host framework's) is not this call's */
     int rc = RTR_OK;
@@ -994,13 +1006,13 @@ int rtr_render_device(rtr_context* c, const rtr_render_params* p, double* d_rgb,
         plan.trav = trav;
         plan.machine = (p->flags & RTR_FLAG_WF_PERSISTENT) != 0;
         rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), plan, P, p->integrator, d_rgb, row_stride,
-                              c->stream, &c->cancelled_upto, &launches, c->err);
+                              tile_done, c->stream, &c->cancelled_upto, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
         if (rc == RTR_ERR_CANCELLED) c->stats.cancelled = 1;
         c->stats.kernel_launches = launches;
     } else {
         if ((rc = launch_mega(c, P, p->integrator, trav, false, nullptr))) return rc;
-        ResolveK R{P, d_rgb, (long long)row_stride};
+        ResolveK R{P, d_rgb, (long long)row_stride, tile_done};
         rtr_launch_resolve(R, c->stream);
         HIPCHK(c, hipGetLastError());
         c->stats.kernel_launches = 2;
@@ -1040,6 +1052,48 @@ int rtr_render_host(rtr_context* c, const rtr_render_params* p, double* h_rgb, i
         if (e2 != hipSuccess) rc = fail(c, RTR_ERR_DEVICE, hipGetErrorString(e2));
     }
     return rc;
+}
+
+int rtr_render_tiles_host(rtr_context* c, const rtr_render_params* p, const double** tiles, const int32_t** tile_ids,
+                          const uint8_t** tile_done, int64_t* n_tiles) {
+    if (!c) return RTR_ERR_INVALID;
+    if (!c->has_scene) return fail(c, RTR_ERR_NO_SCENE, "rtr_render before rtr_upload_scene");
+    if (int prc = params_check(c, p)) return prc;
+    if (!tiles || !tile_ids || !tile_done || !n_tiles) return fail(c, RTR_ERR_INVALID, "null output pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    int tx, ty;
+    const std::vector<int> owned = owned_tiles(*p, tx, ty);
+    const size_t n = owned.size();
+    /* [pixels: n x 768 doubles][done: n bytes, padded][ids: n int32] -- on the device and, pinned, on the host */
+    const size_t px_bytes = n * 768 * sizeof(double), done_bytes = (n + 15) & ~(size_t)15, id_bytes = n * sizeof(int32_t);
+    const size_t total = px_bytes + done_bytes + id_bytes + 16;
+    if (total > c->b_stage.cap || total > c->h_stage_cap) HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = ensure(c, c->b_stage, total);
+    if (rc) return rc;
+    if (total > c->h_stage_cap) {
+        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr, c->h_stage_cap = 0;
+        if (hipHostMalloc(&c->h_stage, total, hipHostMallocDefault) != hipSuccess)
+            return fail(c, RTR_ERR_NOMEM, "hipHostMalloc of the tile staging buffer");
+        c->h_stage_cap = total;
+    }
+    char* d = static_cast<char*>(c->b_stage.p);
+    char* h = static_cast<char*>(c->h_stage);
+    *n_tiles = (int64_t)n;
+    *tiles = reinterpret_cast<const double*>(h);
+    *tile_done = reinterpret_cast<const uint8_t*>(h + px_bytes);
+    *tile_ids = reinterpret_cast<const int32_t*>(h + px_bytes + done_bytes);
+    if (n == 0) return RTR_OK;
+    std::memcpy(h + px_bytes + done_bytes, owned.data(), id_bytes);
+    HIPCHK(c, hipMemsetAsync(d + px_bytes, 0, done_bytes, c->stream));
+    rc = render_core(c, p, reinterpret_cast<double*>(d), -1, reinterpret_cast<unsigned char*>(d + px_bytes), 0);
+    if (rc && rc != RTR_ERR_CANCELLED) return rc;
+    /* one D2H of the owned tiles and their flags into pinned memory */
+    HIPCHK(c, hipMemcpyAsync(h, d, px_bytes + done_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int frc = finish_stats(c)) return frc;
+    if (c->stats.cancelled) return fail(c, RTR_ERR_CANCELLED, "render cancelled");
+    return RTR_OK;
 }
 
 int rtr_plan_chunks(rtr_context* c, const rtr_render_params* p) {

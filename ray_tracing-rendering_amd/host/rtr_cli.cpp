@@ -4,7 +4,7 @@
  * overrides the BASELINE configurations need (--width --spp --seed --out).  It is the
  * reference-side usage of the host layer: select_scene -> camera -> Renderer::render -> file.
  *
- *   rtr_cli <scene 7|9|21|22|23> <integrator 0..4> [--width W] [--spp N] [--seed S] [--bands N] [--out img.ppm]
+ *   rtr_cli <scene 7|9|21|22|23> <integrator 0..4> [--width W] [--spp N] [--seed S] [--bands N] [--out img.ppm|img.png]
  *           [--devices 0,1,...|all] [--repeat N]   one context + host thread per listed GPU (an ordinal may repeat)
  */
 #include "rtr_renderer.h"
@@ -72,7 +72,8 @@ int main(int argc, char** argv) {
     std::cout << "contexts: " << renderer.device_contexts() << "  scene uploads: " << renderer.scene_uploads() << "\n";
     std::cout << "Msamples/s: " << (double)W * H * config.samples_per_pixel / renderer.last_seconds() * 1e-6
               << " (includes flatten, upload and D2H)\n";
-    if (!out.empty() && !buffer.save_to_ppm(out)) {
+    const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0; /* main.cpp:138-151 writes a PNG */
+    if (!out.empty() && !(png ? buffer.save_to_png(out) : buffer.save_to_ppm(out))) {
         std::cerr << "Failed to save image to " << out << "\n";
         return 1;
     }

@@ -226,6 +226,34 @@ int rtr_host_output_stage(const double* linear, int width, int height, uint8_t* 
     return RTR_OK;
 }
 
+/* RenderBuffer::save_to_png / save_to_jpg of the host layer (render_buffer.h:35-80) on a linear image; returns 1 / 0
+ * like the methods.  For the packed-tile path the image goes in through store_linear_tile, 16x16 tile by tile, the way
+ * a Renderer worker stores what rtr_render_tiles_host returns. */
+int rtr_host_save_png(const double* linear, int width, int height, const char* path, int through_tiles) {
+    if (!linear || !path || width <= 0 || height <= 0) return 0;
+    RenderBuffer buf(width, height);
+    if (!through_tiles) {
+        buf.store_linear_rows(linear, 0, height, width);
+    } else {
+        double tile[768];
+        for (int ty = 0; ty < height; ty += 16)
+            for (int tx = 0; tx < width; tx += 16) {
+                for (int r = 0; r < 16; ++r)
+                    for (int q = 0; q < 16; ++q)
+                        for (int c = 0; c < 3; ++c)
+                            tile[(r * 16 + q) * 3 + c] = (ty + r < height && tx + q < width)
+                                                             ? linear[((size_t)(ty + r) * width + tx + q) * 3 + c]
+                                                             : -1.0; /* outside the image: must never be stored */
+                buf.store_linear_tile(tile, tx, ty, 0, height);
+            }
+    }
+    return buf.save_to_png(path) ? 1 : 0;
+}
+int rtr_host_save_jpg(int width, int height, const char* path) {
+    RenderBuffer buf(width, height);
+    return buf.save_to_jpg(path) ? 1 : 0;
+}
+
 /* tile bookkeeping of the multi-context Renderer (host/rtr_renderer.h), for the CPU tests */
 int rtr_host_tile_owner(int width, int height, int i, int j, int n_workers) { return rtr::tile_owner(width, height, i, j, n_workers); }
 

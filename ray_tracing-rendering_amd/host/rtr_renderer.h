@@ -19,7 +19,10 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <thread>
+
+#include <zlib.h>
 
 class RenderBuffer {
   public:
@@ -54,7 +57,66 @@ class RenderBuffer {
             }
         return out;
     }
-    /* binary PPM of those bytes (the reference encodes them as PNG with stb_image_write: out of scope) */
+    /* write_color_to_buffer for the pixels of one packed 16x16 tile (include/rtr_hip.h: rtr_render_tiles_host) that lie
+     * inside rows [y0, y1): tile origin (tx0, ty0), `px` = 16 rows of 16 pixels of 3 doubles, lowest row first */
+    void store_linear_tile(const double* px, int tx0, int ty0, int y0, int y1) {
+        for (int r = 0; r < 16; ++r) {
+            const int j = ty0 + r;
+            if (j < y0 || j >= y1 || j >= m_height) continue;
+            for (int q = 0; q < 16; ++q) {
+                const int i = tx0 + q;
+                if (i >= m_width) break;
+                const double* v = &px[(r * 16 + q) * 3];
+                m_pixels[j][i] = color(clamp(sqrt(v[0]), 0.0, 1.0), clamp(sqrt(v[1]), 0.0, 1.0), clamp(sqrt(v[2]), 0.0, 1.0));
+            }
+        }
+    }
+    /* render_buffer.h:35-55: the bytes of to_rgb8() as an 8-bit RGB PNG.  The reference hands them to stb_image_write;
+     * here a plain encoder (filter 0 on every row, one zlib stream): another compressed byte stream, the same pixels
+     * (tests/test_output_stage.py decodes the file and compares them with the reference's own PNG). */
+    bool save_to_png(const std::string& filename) const {
+        const std::vector<unsigned char> rgb = to_rgb8();
+        std::vector<unsigned char> raw((size_t)m_height * (1 + (size_t)m_width * 3));
+        for (int j = 0; j < m_height; ++j) {
+            raw[(size_t)j * (1 + (size_t)m_width * 3)] = 0;
+            std::memcpy(&raw[(size_t)j * (1 + (size_t)m_width * 3) + 1], &rgb[(size_t)j * m_width * 3], (size_t)m_width * 3);
+        }
+        uLongf zlen = compressBound((uLong)raw.size());
+        std::vector<unsigned char> z(zlen);
+        if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+        FILE* f = std::fopen(filename.c_str(), "wb");
+        if (!f) return false;
+        auto be32 = [](unsigned char* p, unsigned long v) { p[0] = v >> 24, p[1] = v >> 16, p[2] = v >> 8, p[3] = v; };
+        bool ok = true;
+        auto chunk = [&](const char* type, const unsigned char* data, size_t len) {
+            unsigned char head[8];
+            be32(head, (unsigned long)len);
+            std::memcpy(head + 4, type, 4);
+            unsigned long crc = crc32(0L, head + 4, 4);
+            if (len) crc = crc32(crc, data, (uInt)len);
+            unsigned char tail[4];
+            be32(tail, crc);
+            ok = ok && std::fwrite(head, 1, 8, f) == 8 && (len == 0 || std::fwrite(data, 1, len, f) == len) &&
+                 std::fwrite(tail, 1, 4, f) == 4;
+        };
+        static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+        ok = std::fwrite(sig, 1, 8, f) == 8;
+        unsigned char ihdr[13];
+        be32(ihdr, (unsigned long)m_width), be32(ihdr + 4, (unsigned long)m_height);
+        ihdr[8] = 8, ihdr[9] = 2, ihdr[10] = 0, ihdr[11] = 0, ihdr[12] = 0; /* 8 bits, RGB, deflate, adaptive filters, no interlace */
+        chunk("IHDR", ihdr, 13);
+        chunk("IDAT", z.data(), (size_t)zlen);
+        chunk("IEND", nullptr, 0);
+        return std::fclose(f) == 0 && ok;
+    }
+    /* render_buffer.h:58-80 writes a JPEG through stb_image_write's encoder, which is outside this path:
+     * the method exists so the reference's callers compile; it reports failure like a file that cannot be written. */
+    bool save_to_jpg(const std::string& filename, int quality = 90) const {
+        (void)quality;
+        std::cerr << "save_to_jpg(" << filename << "): no JPEG encoder in this build; use save_to_png\n";
+        return false;
+    }
+    /* binary PPM of those bytes */
     bool save_to_ppm(const std::string& filename) const {
         FILE* f = std::fopen(filename.c_str(), "wb");
         if (!f) return false;
@@ -160,9 +222,10 @@ class Renderer {
         for (int d : devices) {
             rtr_context* c = nullptr;
             const int rc = rtr_create(d, &c);
-            if (rc != RTR_OK) {
-                m_status = rc;
-                std::cerr << "rtr_create(" << d << "): " << rtr_last_error(nullptr) << "\n";
+            if (rc != RTR_OK) { /* render() refuses: an image from fewer GPUs than asked for would pass for the real one */
+                m_create_status = rc;
+                m_create_error = std::string("rtr_create(") + std::to_string(d) + "): " + rtr_last_error(nullptr);
+                std::cerr << m_create_error << "\n";
                 continue;
             }
             m_ctx.push_back(c);
@@ -187,9 +250,9 @@ class Renderer {
     }
     void set_seed(uint32_t seed) { m_seed = seed; } /* the reference has no seed control */
     /* The reference's workers store pixels as they finish tiles and main.cpp:124 polls
-     * RenderBuffer::get_data() meanwhile.  Here the image is rendered in `n` horizontal bands of whole
-     * tile rows, top band first like the reference's tile order (renderer.h:61-62), and every band is
-     * stored as soon as it arrives; cancel() takes effect between bands, too.  0 = pick by image
+     * RenderBuffer::get_data() meanwhile.  Here every context renders the image in `n` horizontal bands of whole
+     * tile rows, top band first like the reference's tile order (renderer.h:61-62), and stores the tiles it owns
+     * as soon as they arrive; cancel() takes effect inside and between bands.  0 = pick by image
      * height (one band per 256 rows).  Per-sample seeds depend on (pixel, sample) only, so the
      * result does not depend on n. */
     void set_progress_bands(int n) { m_bands = n; }
@@ -228,6 +291,7 @@ class Renderer {
   private:
     int render_impl(const hittable& world, const camera& cam, const color& background, RenderBuffer& buf,
                     const std::vector<shared_ptr<Light>>& lights, bool scene_on_device) {
+        if (m_create_status != RTR_OK) return m_error = m_create_error, m_create_status;
         if (m_ctx.empty()) return m_error = rtr_last_error(nullptr), RTR_ERR_DEVICE;
         if (!m_integrator) return m_error = "no integrator set", RTR_ERR_INVALID;
         const int n = (int)m_ctx.size();
@@ -257,40 +321,58 @@ class Renderer {
         p.pipeline = RTR_PIPELINE_AUTO;
         p.spp_chunks = 0;
         int bands = m_bands > 0 ? m_bands : (H + 255) / 256;
-        const int tile_rows = (H + 15) / 16;
+        const int tile_rows = (H + 15) / 16, tiles_x = (W + 15) / 16;
         bands = std::max(1, std::min(bands, tile_rows));
-        std::vector<std::vector<double>> lin(n);
+        /* One worker per context, like the reference's one worker per hardware thread (renderer.h:48-94): worker k
+         * walks the bands top to bottom on its own, renders the tiles index % n == k of each (nothing is uploaded, the
+         * tiles it owns come back packed through pinned memory: rtr_render_tiles_host) and stores them into the
+         * RenderBuffer itself -- distinct pixels, so no lock and no join per band; the polling UI (main.cpp:124) sees
+         * tiles appear as they finish.  After a cancel the finished tiles of the band are stored, the others keep their
+         * previous pixels (renderer.h:52-59). */
         std::vector<int> rcs(n, RTR_OK);
-        for (int b = 0; b < bands; ++b) { /* row 0 of the buffer is the bottom row; the top band goes first */
-            const int r1 = tile_rows - (int)((long long)b * tile_rows / bands);
-            const int r0 = tile_rows - (int)((long long)(b + 1) * tile_rows / bands);
-            const int y0 = r0 * 16, y1 = std::min(H, r1 * 16);
-            if (y0 >= y1) continue;
-            if (!m_is_rendering) return m_error = "render cancelled", RTR_ERR_CANCELLED;
-            p.y0 = y0, p.y1 = y1;
-            auto work = [&](int k) { /* context k: tiles index % n == k of this band, into its own host buffer */
-                rtr_render_params q = p;
-                q.tile_first = k, q.tile_stride = n;
-                lin[k].assign((size_t)W * (y1 - y0) * 3, 0.0);
-                rcs[k] = rtr_render_host(m_ctx[k], &q, lin[k].data(), W);
-            };
-            if (n == 1) {
-                work(0);
-            } else {
-                std::vector<std::thread> th;
-                for (int k = 0; k < n; ++k) th.emplace_back(work, k);
-                for (auto& t : th) t.join();
+        std::vector<std::string> errs(n);
+        auto work = [&](int k) {
+            rtr_render_params q = p;
+            q.tile_first = k, q.tile_stride = n;
+            for (int b = 0; b < bands; ++b) { /* row 0 of the buffer is the bottom row; the top band goes first */
+                const int r1 = tile_rows - (int)((long long)b * tile_rows / bands);
+                const int r0 = tile_rows - (int)((long long)(b + 1) * tile_rows / bands);
+                const int y0 = r0 * 16, y1 = std::min(H, r1 * 16);
+                if (y0 >= y1) continue;
+                if (!m_is_rendering) {
+                    rcs[k] = RTR_ERR_CANCELLED, errs[k] = "render cancelled";
+                    return;
+                }
+                q.y0 = y0, q.y1 = y1;
+                const double* tiles = nullptr;
+                const int32_t* ids = nullptr;
+                const uint8_t* done = nullptr;
+                int64_t n_tiles = 0;
+                const int rc = rtr_render_tiles_host(m_ctx[k], &q, &tiles, &ids, &done, &n_tiles);
+                if (rc != RTR_OK && rc != RTR_ERR_CANCELLED) {
+                    rcs[k] = rc, errs[k] = rtr_last_error(m_ctx[k]);
+                    return;
+                }
+                for (int64_t t = 0; t < n_tiles; ++t) {
+                    if (!done[t]) continue;
+                    const int ty = (tile_rows - 1) - ids[t] / tiles_x, tx = ids[t] % tiles_x; /* renderer.h:61-62 */
+                    buf.store_linear_tile(tiles + t * 768, tx * 16, ty * 16, y0, y1);
+                }
+                if (rc == RTR_ERR_CANCELLED) {
+                    rcs[k] = rc, errs[k] = "render cancelled";
+                    return;
+                }
             }
-            for (int k = 0; k < n; ++k)
-                if (rcs[k]) return m_error = rtr_last_error(m_ctx[k]), rcs[k];
-            if (n > 1) /* every pixel from the context that owns its tile */
-                for (int j = y0; j < y1; ++j)
-                    for (int i = 0; i < W; ++i) {
-                        const int k = rtr::tile_owner(W, H, i, j, n);
-                        if (k) std::memcpy(&lin[0][((size_t)(j - y0) * W + i) * 3], &lin[k][((size_t)(j - y0) * W + i) * 3], 24);
-                    }
-            buf.store_linear_rows(lin[0].data(), y0, y1, W);
+        };
+        if (n == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < n; ++k) th.emplace_back(work, k);
+            for (auto& t : th) t.join();
         }
+        for (int k = 0; k < n; ++k)
+            if (rcs[k]) return m_error = errs[k], rcs[k];
         return RTR_OK;
     }
 
@@ -305,6 +387,8 @@ class Renderer {
     bool m_scene_valid = false;
     int m_scene_uploads = 0;
     int m_status = RTR_OK;
+    int m_create_status = RTR_OK; /* a context that could not be created: render() refuses */
+    std::string m_create_error;
     uint32_t m_seed = 1;
     int m_bands = 0;
     double m_seconds = 0;

@@ -19,7 +19,7 @@ _STATUS = {A.RTR_ERR_INVALID: "RTR_ERR_INVALID", A.RTR_ERR_UNSUPPORTED: "RTR_ERR
 
 # every symbol include/rtr_hip.h declares (librtr_hip.so) ...
 EXPORTS = ("rtr_abi_version", "rtr_device_count", "rtr_create", "rtr_destroy", "rtr_set_stream",
-           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_li_rays",
+           "rtr_upload_scene", "rtr_render_device", "rtr_render_host", "rtr_render_tiles_host", "rtr_plan_chunks", "rtr_li_samples", "rtr_li_rays",
            "rtr_synchronize", "rtr_cancel", "rtr_get_stats", "rtr_last_error", "rtr_sample_seed", "rtr_validate_scene")
 # ... and include/rtr_hip_test.h (librtr_hip_test.so: device unit kernels of the parity tests, not part of the product)
 TEST_EXPORTS = ("rtr_test_hits", "rtr_test_materials", "rtr_test_lights", "rtr_test_li", "rtr_test_reference_order",

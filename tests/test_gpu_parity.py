@@ -893,6 +893,13 @@ def test_cpp_host_renderer_cli(ctx, rtr, tmp_path):
     assert r.returncode == 0, r.stderr
     want = np.fromfile(os.path.join(G.GOLD, "png_scene21_i4_64_spp16.rgb8"), dtype=np.uint8)
     assert np.array_equal(np.frombuffer(open(out_g, "rb").read()[len(head):], dtype=np.uint8), want)
+    # ... and as the PNG main.cpp:138-151 saves (RenderBuffer::save_to_png of the mirror), from two contexts
+    from test_output_stage import _decode_png
+    out_p = str(tmp_path / "cli_golden.png")
+    r = subprocess.run([cli, "21", "4", "--width", "64", "--spp", "16", "--seed", "1", "--devices", "0,0", "--out", out_p],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(_decode_png(out_p).reshape(-1), want)
 
 
 def test_large_flat_list(ctx, rtr):

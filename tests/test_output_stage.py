@@ -73,6 +73,23 @@ def test_cpp_render_buffer_matches_reference_writer(src, fixture):
     assert np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("src,fixture", CASES)
+@pytest.mark.parametrize("through_tiles", [0, 1])
+def test_cpp_render_buffer_png_decodes_to_the_reference_pixels(src, fixture, through_tiles, tmp_path):
+    """host/rtr_renderer.h: RenderBuffer::save_to_png (render_buffer.h:35-55), fed by rows and by packed 16x16 tiles
+    (what a Renderer worker stores): the file decodes to the pixels of the reference's own PNG.  save_to_jpg exists for
+    the reference's callers (main.cpp:138-151 compiles) and reports failure: the JPEG encoder is outside this path."""
+    lin, want, w, h = _load(src, fixture)
+    lib = rtr.hostscene.lib()
+    lib.rtr_host_save_png.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    lin = np.ascontiguousarray(lin)
+    path = str(tmp_path / "cpp.png")
+    assert lib.rtr_host_save_png(lin.ctypes.data, w, h, path.encode(), through_tiles) == 1
+    assert np.array_equal(_decode_png(path), want)
+    lib.rtr_host_save_jpg.argtypes = [C.c_int, C.c_int, C.c_char_p]
+    assert lib.rtr_host_save_jpg(w, h, str(tmp_path / "cpp.jpg").encode()) == 0
+
+
 def test_edge_fixture_covers_every_byte_value_step():
     """the synthetic image walks the sqrt-gamma steps: the fixture must contain clamped, zero and mid values"""
     _, want, _, _ = _load("png_edge_in.f64", "png_edge_in.rgb8")
