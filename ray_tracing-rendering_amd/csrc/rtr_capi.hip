@@ -479,10 +479,14 @@ int choose_chunks(rtr_context* c, RenderK P, int integrator, int pipeline, int t
     guided[0] = guided[1] = guided[2] = 0;
     const double rounds = (double)P.n_tiles * *chunks / resident;
     if (pipeline == RTR_PIPELINE_MEGAKERNEL && *chunks >= 4 && rounds < 30.0 && spp >= 8 * *chunks) {
-        const int n_big = *chunks - *chunks / 4;
-        const int big = (int)((0.90 * spp + n_big - 1) / n_big);
+        /* (RTR_GUIDED = "big-share,small-divisor,big-chunk-eighths" overrides the split for tools/shard_sweep.py) */
+        double share = 0.90;
+        int div = 3, eighths = 6;
+        if (const char* g = getenv("RTR_GUIDED")) std::sscanf(g, "%lf,%d,%d", &share, &div, &eighths);
+        const int n_big = std::max(1, *chunks * eighths / 8);
+        const int big = (int)((share * spp + n_big - 1) / n_big);
         const int rem = spp - n_big * big;
-        const int small = std::max(1, big / 3);
+        const int small = std::max(1, big / std::max(1, div));
         if (rem > 0) {
             const int n_small = (rem + small - 1) / small;
             guided[0] = n_big, guided[1] = big, guided[2] = small;

@@ -86,7 +86,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_gather_is_bit_identical_to_one_rank():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_gather_is_bit_identical_to_one_rank(world):
+    """world 2, and the BASELINE's 8: a 40x40 image has 9 tiles, so with 8 ranks the shares are ragged (rank 0 owns two
+    tiles, the others one) -- the N = 8 gather and coverage bookkeeping run here even where no 8-GPU node is at hand."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -94,7 +97,7 @@ def test_two_rank_gloo_gather_is_bit_identical_to_one_rank():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

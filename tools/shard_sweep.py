@@ -19,7 +19,7 @@ with pkg.Context(0) as ctx:
     base = None
     for n in (1, 2, 4, 8):
         row = []
-        for chunks in (0, 4, 8, 16, 32, 64):
+        for chunks in (0, 4, 6, 8, 9, 10, 11, 12, 13, 14, 16, 20, 26, 32):
             p = A.make_params(W, H, spp, integrator=integ, seed=1, tile_first=0, tile_stride=n, spp_chunks=chunks)
             best = 1e9
             for _ in range(3):
