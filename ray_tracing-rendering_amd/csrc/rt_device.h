@@ -282,6 +282,7 @@ struct DScene {
     const struct FRef* fref;
     const rtr_node* fprim; /* copy of the primitive's node record per reference (one load hop less) */
     const double* fscan;   /* packed geometry of linearly scanned references (see FInst) */
+    const struct FMat* fmat; /* per material: its record with the values of its solid_color textures inline (see FMat) */
     const struct FLeaf* fleaf; /* leaf records of the box trees, one per reference (see FLeaf) */
     const int32_t* fexit;
     const struct FBvh* fbvh;
@@ -359,6 +360,17 @@ struct FBvh {
     int32_t pad[2];
 };
 #define RT_BVH_DONE (-2147483647 - 1) /* traversal sentinel: nothing left on the stack */
+/* One record per material for mat_prepare: the rtr_material plus, where every texture it reads is a solid_color
+ * (texture.h:46-48: value() returns the colour whatever (u, v, p) are), those values -- one fetch per hit instead of the
+ * material and then up to three texture records behind it.  `solid` = 0: mat_prepare takes the textures' own path. */
+struct FMat {
+    int32_t type, solid;
+    int32_t tex[4];
+    int32_t pad[2];
+    double f[4];
+    double albedo[3];    /* value of tex[0] */
+    double rough, metal; /* PBR: tex[1] clamped to [0.01, 1] (material.h:264,327,368), tex[2] */
+};
 /* What a lane fetches per reference of a tree leaf: 64 bytes instead of the 96-byte node record.  (A leaf holding the six
  * sides of a `box` as ONE record -- one fetch, three shared reciprocals, the six rectangle tests in list order -- was built
  * and measured: half the leaf instructions, bit-identical, and 3 % SLOWER on scenes 9 / 22 (1 459 vs 1 510 Msamples/s): the
@@ -1625,7 +1637,8 @@ RT_DEV Real pow5(Real x) {
 RT_DEV V3 fresnel_schlick(Real cosTheta, V3 F0) { /* material.h:430-432 */
     return add(F0, scl(pow5(1.0 - cosTheta), sub(mk(1, 1, 1), F0)));
 }
-RT_DEV V3 pbr_normal(const DScene& sc, const rtr_material& m, const Hit& rec) { /* material.h:247-261 */
+template <class M>
+RT_DEV V3 pbr_normal(const DScene& sc, const M& m, const Hit& rec) { /* material.h:247-261 */
     V3 N = rec.n;
     if (m.tex[3] >= 0) {
         V3 ax0;
@@ -1726,11 +1739,16 @@ RT_DEV Real reflectance(Real cosine, Real ref_idx) { /* material.h:199-203 */
 template <int MS = RT_MS_FULL>
 RT_DEV MatCtx mat_prepare(const DScene& sc, const Hit& rec) {
     RT_REGION(RG_MATPREP);
-    const rtr_material m = ld_const(sc.materials, rec.mat); /* constant address space: never a flat load */
+    const FMat m = ld_const(sc.fmat, rec.mat); /* constant address space: never a flat load */
     MatCtx c;
     c.type = m.type;
     c.f0 = m.f[0], c.f1 = m.f[1], c.f2 = m.f[2], c.f3 = m.f[3];
     c.albedo = mk(0, 0, 0), c.N = rec.n, c.rough = 0, c.metal = 0;
+    if (MS == RT_MS_LEAN || m.solid) { /* every texture the material reads is a constant: its values came with the record */
+        c.albedo = ld3(m.albedo);
+        c.rough = m.rough, c.metal = m.metal;
+        return c;
+    }
     if (c.type == RTR_MAT_LAMBERTIAN || c.type == RTR_MAT_DIFFUSE_LIGHT) {
         c.albedo = tex_value<MS>(sc, m.tex[0], rec.u, rec.v, rec.p);
     } else if (MS != RT_MS_LEAN && c.type == RTR_MAT_ISOTROPIC) {
@@ -1759,24 +1777,30 @@ RT_DEV V3 mat_emitted_legacy(const MatCtx& c) {
 __device__ __forceinline__ bool pbr_sample(const MatCtx& c, V3 wo, BSDFSample& s, uint32_t& rng) {
     const V3 N = c.N;
     const Real rough = c.rough;
-    if (rng_next(rng) < 0.5) {
-        Onb uvw = onb_from_w(N);
-        Real r1 = rng_next(rng);
-        Real r2 = rng_next(rng);
+    /* Both branches of material.h:263-302 build the same basis around N, draw r1 then r2 and take cos / sin of
+     * 2 pi r1 (the cosine branch inside random_cosine_direction, vec3.h:261-269): done once here for the whole wave,
+     * which nearly always holds lanes of both branches; each lane then finishes its own branch with its own operands */
+    const bool ggx = rng_next(rng) < 0.5;
+    const Onb uvw = onb_from_w(N);
+    const Real r1 = rng_next(rng);
+    const Real r2 = rng_next(rng);
+    const Real phi = 2.0 * RT_PI * r1;
+    Real sphi, cphi; /* one argument reduction for both (see random_cosine_direction) */
+    sincos(phi, &sphi, &cphi);
+    if (ggx) {
         Real a = rough * rough;
-        Real phi = 2.0 * RT_PI * r1;
         Real cos_theta = __builtin_sqrt((1.0 - r2) / (1.0 + (a * a - 1.0) * r2));
         Real sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
-        Real sphi, cphi; /* cos(phi), sin(phi) of material.h:272-274 from one argument reduction (see random_cosine_direction) */
-        sincos(phi, &sphi, &cphi);
         V3 H_local = mk(sin_theta * cphi, sin_theta * sphi, cos_theta);
         V3 H = onb_local(uvw, H_local);
         V3 L = reflect(neg(wo), H);
         if (dot(N, L) <= 0) return false;
         s.wi = L;
     } else {
-        Onb uvw = onb_from_w(N);
-        V3 L = onb_local(uvw, random_cosine_direction(rng));
+        const Real z = __builtin_sqrt(1 - r2); /* vec3.h:261-269 */
+        const Real x = cphi * __builtin_sqrt(r2);
+        const Real y = sphi * __builtin_sqrt(r2);
+        V3 L = onb_local(uvw, mk(x, y, z));
         if (dot(N, L) <= 0) L = N;
         s.wi = unit(L);
     }

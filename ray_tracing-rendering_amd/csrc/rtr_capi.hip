@@ -41,7 +41,7 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan, b_fleaf;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan, b_fleaf, b_fmat;
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
@@ -630,7 +630,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_done, &c->b_stats, &c->b_cancel, &c->b_test, &c->b_stage,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit, &c->b_fscan, &c->b_fleaf};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit, &c->b_fscan, &c->b_fleaf, &c->b_fmat};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -909,6 +909,34 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
             for (int q = 0; q < n_tex; ++q)
                 if (tex_reads_uv(m.tex[q], 0)) c->uv_order_dependent = true;
         }
+    }
+    { /* FMat: materials with their solid textures' values inline */
+        std::vector<FMat> fm((size_t)s->n_materials);
+        auto solid = [&](int t) { return t >= 0 && s->textures[t].type == RTR_TEX_SOLID; };
+        auto clampd = [](double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }; /* rtweekend.h:40-46 */
+        for (int k = 0; k < s->n_materials; ++k) {
+            const rtr_material& m = s->materials[k];
+            FMat f{};
+            f.type = m.type;
+            for (int q = 0; q < 4; ++q) f.tex[q] = m.tex[q], f.f[q] = m.f[q];
+            switch (m.type) {
+            case RTR_MAT_LAMBERTIAN:
+            case RTR_MAT_DIFFUSE_LIGHT:
+            case RTR_MAT_ISOTROPIC: f.solid = solid(m.tex[0]); break;
+            case RTR_MAT_PBR: f.solid = solid(m.tex[0]) && solid(m.tex[1]) && solid(m.tex[2]) && m.tex[3] < 0; break;
+            default: f.solid = 1; /* metal, dielectric: no texture */
+            }
+            if (f.solid && m.type != RTR_MAT_METAL && m.type != RTR_MAT_DIELECTRIC) {
+                for (int q = 0; q < 3; ++q) f.albedo[q] = s->textures[m.tex[0]].f[q];
+                if (m.type == RTR_MAT_PBR) {
+                    f.rough = clampd(s->textures[m.tex[1]].f[0], 0.01, 1.0);
+                    f.metal = s->textures[m.tex[2]].f[0];
+                }
+            }
+            fm[(size_t)k] = f;
+        }
+        if ((rc = upload(c, c->b_fmat, fm.data(), sizeof(FMat) * fm.size()))) return rc;
+        d.fmat = static_cast<const FMat*>(c->b_fmat.p);
     }
     if ((rc = upload(c, c->b_dscene, &c->ds, sizeof(DScene)))) return rc;
     c->has_scene = true;
