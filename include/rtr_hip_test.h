@@ -39,7 +39,9 @@ int rtr_test_sincos_exhaustive(rtr_context* ctx, uint64_t* mismatches);
 /* Measured issue costs for bench.py's `valu_slot_utilisation`: shader cycles a wave spends per instruction of one class
  * while four waves share each SIMD (so a pipe-bound class reads four times its pipe cost), classes in this order:
  * v_fma_f64, v_add_f64, v_mul_f64, v_rcp_f64, v_rsq_f64, v_cmp_lt_f64, v_cndmask_b32, v_mov_b32, v_fma_f32, s_and_b64,
- * v_div_scale_f64, v_div_fixup_f64, {v_cmp_lt_f64 + dependent s_and_b64}.  Fills cycles_per_inst[0 .. n) (n <= 13). */
+ * v_div_scale_f64, v_div_fixup_f64, {v_cmp_lt_f64 + dependent s_and_b64}, v_cndmask_b32 with a scalar-pair mask, v_min_f32,
+ * {v_cmp_lt_f32 + v_cndmask_b32}, v_cndmask_b32 into four destinations, {v_cmp_lt_f64 + v_cndmask_b32}.  Fills
+ * cycles_per_inst[0 .. n) (n <= 18). */
 int rtr_test_issue_rates(rtr_context* ctx, double* cycles_per_inst, int n);
 
 /* The primitive tests divide many numerators by the same ray-direction component through a shared refined reciprocal

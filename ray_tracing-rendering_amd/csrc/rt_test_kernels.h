@@ -154,7 +154,7 @@ template <int KIND>
 __global__ void __launch_bounds__(RTR_BLOCK) k_test_issue_rate(unsigned long long* out, int iters, double seed) {
     double a = seed + threadIdx.x, b = seed * 0.5, c = 1.0 / (seed + 3.0), d = seed;
     float fa = (float)a, fb = (float)b, fc = (float)c;
-    int ia = threadIdx.x, ib = 3;
+    int ia = threadIdx.x, ib = 3, ic = 0;
     unsigned long long m = 0;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; ++i) {
@@ -164,17 +164,22 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_issue_rate(unsigned long lon
         if (KIND == 3) asm volatile(RT_REP32("v_rcp_f64 %0, %1\n") : "+v"(d) : "v"(b));
         if (KIND == 4) asm volatile(RT_REP32("v_rsq_f64 %0, %1\n") : "+v"(d) : "v"(b));
         if (KIND == 5) asm volatile(RT_REP32("v_cmp_lt_f64 %0, %1, %2\n") : "=s"(m) : "v"(b), "v"(c));
-        if (KIND == 6) asm volatile(RT_REP32("v_cndmask_b32 %0, %1, %2, vcc\n") : "+v"(ia) : "v"(ib), "v"(ia) : "vcc");
+        if (KIND == 6) asm volatile(RT_REP32("v_cndmask_b32 %0, %1, %2, vcc\n") : "=v"(ic) : "v"(ib), "v"(ia) : "vcc");
         if (KIND == 7) asm volatile(RT_REP32("v_mov_b32 %0, %1\n") : "+v"(ia) : "v"(ib));
         if (KIND == 8) asm volatile(RT_REP32("v_fma_f32 %0, %1, %2, %1\n") : "+v"(fa) : "v"(fb), "v"(fc));
         if (KIND == 9) asm volatile(RT_REP32("s_and_b64 %0, %0, exec\n") : "+s"(m) : : "scc");
         if (KIND == 10) asm volatile(RT_REP32("v_div_scale_f64 %0, vcc, %1, %2, %1\n") : "+v"(d) : "v"(b), "v"(c) : "vcc");
         if (KIND == 11) asm volatile(RT_REP32("v_div_fixup_f64 %0, %1, %2, %1\n") : "+v"(d) : "v"(b), "v"(c));
+        if (KIND == 13) asm volatile(RT_REP32("v_cndmask_b32_e64 %0, %1, %2, %3\n") : "=v"(ic) : "v"(ib), "v"(ia), "s"(m));
+        if (KIND == 14) asm volatile(RT_REP32("v_min_f32 %0, %1, %2\n") : "=v"(fa) : "v"(fb), "v"(fc));
+        if (KIND == 15) asm volatile(RT_REP32("v_cmp_lt_f32 vcc, %1, %2\nv_cndmask_b32 %0, %1, %2, vcc\n") : "=v"(fa) : "v"(fb), "v"(fc) : "vcc");
+        if (KIND == 16) { int i0, i1, i2, i3; asm volatile(RT_REP32("v_cndmask_b32 %0, %4, %5, vcc\nv_cndmask_b32 %1, %4, %5, vcc\nv_cndmask_b32 %2, %4, %5, vcc\nv_cndmask_b32 %3, %4, %5, vcc\n") : "=v"(i0), "=v"(i1), "=v"(i2), "=v"(i3) : "v"(ib), "v"(ia) : "vcc"); ic = i0 + i1 + i2 + i3; }
+        if (KIND == 17) asm volatile(RT_REP32("v_cmp_lt_f64 vcc, %1, %2\nv_cndmask_b32 %0, %3, %4, vcc\n") : "=v"(ic) : "v"(b), "v"(c), "v"(ib), "v"(ia) : "vcc");
         if (KIND == 12) /* the rectangle test's mix: one compare into a scalar pair and the scalar AND that uses it */
             asm volatile(RT_REP32("v_cmp_lt_f64 %0, %1, %2\ns_and_b64 %0, %0, exec\n") : "=s"(m) : "v"(b), "v"(c) : "scc");
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
-    if (d == 12345.678 || fa == 1.5f || ia == -77 || m == 0x1234567ull) out[2] = 1; /* keep the results alive */
+    if (d == 12345.678 || fa == 1.5f || ia == -77 || ic == -78 || m == 0x1234567ull) out[2] = 1; /* keep the results alive */
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&out[0], t1 - t0);
         atomicAdd(&out[1], 1ull);

@@ -216,18 +216,19 @@ int rtr_test_issue_rates(rtr_context* c, double* cycles_per_inst, int n) {
     auto* d = static_cast<unsigned long long*>(t->buf);
     const int iters = 4096;
     const dim3 grid((unsigned)(n_cus * 4));
-    for (int k = 0; k < n && k < 13; ++k) {
+    for (int k = 0; k < n && k < 18; ++k) {
         TCHK(c, hipMemsetAsync(d, 0, 32, stream));
 #define RTR_RATE(K) case K: hipLaunchKernelGGL(k_test_issue_rate<K>, grid, dim3(RTR_BLOCK), 0, stream, d, iters, 1.25); break
         switch (k) {
             RTR_RATE(0); RTR_RATE(1); RTR_RATE(2); RTR_RATE(3); RTR_RATE(4); RTR_RATE(5); RTR_RATE(6);
             RTR_RATE(7); RTR_RATE(8); RTR_RATE(9); RTR_RATE(10); RTR_RATE(11); RTR_RATE(12);
+            RTR_RATE(13); RTR_RATE(14); RTR_RATE(15); RTR_RATE(16); RTR_RATE(17);
         }
 #undef RTR_RATE
         TCHK(c, hipGetLastError());
         unsigned long long h[2] = {0, 0};
         TCHK(c, hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
-        cycles_per_inst[k] = h[1] ? (double)h[0] / (double)h[1] / (32.0 * iters * (k == 12 ? 2 : 1)) : 0.0;
+        cycles_per_inst[k] = h[1] ? (double)h[0] / (double)h[1] / (32.0 * iters * (k == 12 || k == 15 || k == 17 ? 2 : (k == 16 ? 4 : 1))) : 0.0;
     }
     return RTR_OK;
 }

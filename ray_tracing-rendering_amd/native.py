@@ -241,7 +241,9 @@ class Context:
         return int(n.value)
 
     ISSUE_CLASSES = ("v_fma_f64", "v_add_f64", "v_mul_f64", "v_rcp_f64", "v_rsq_f64", "v_cmp_lt_f64", "v_cndmask_b32",
-                     "v_mov_b32", "v_fma_f32", "s_and_b64", "v_div_scale_f64", "v_div_fixup_f64", "v_cmp_f64+s_and_b64")
+                     "v_mov_b32", "v_fma_f32", "s_and_b64", "v_div_scale_f64", "v_div_fixup_f64", "v_cmp_f64+s_and_b64",
+                     "v_cndmask_b32 (scalar-pair mask)", "v_min_f32", "v_cmp_f32+v_cndmask_b32", "v_cndmask_b32 (4 destinations)",
+                     "v_cmp_f64+v_cndmask_b32")
 
     def issue_rates(self):
         """Shader cycles per wave-instruction and class with four waves on every SIMD (include/rtr_hip_test.h)."""
