@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=2)
     ap.add_argument("--extra-warmup", type=int, default=1)
     ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wavefront"])
+    ap.add_argument("--sorted-shading", action="store_true",
+                    help="experiment: RTR_FLAG_SORTED_SHADING on the timed renders (invalidates the headline)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-spp crop check against the oracle")
@@ -327,7 +329,8 @@ def main():
         ctx.upload(scene)
         fb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
         params = A.make_params(W, H, spp, integrator=wl["integ"], seed=1, pipeline=pipeline, spp_chunks=0,
-                               tile_first=first, tile_stride=stride)
+                               tile_first=first, tile_stride=stride,
+                               flags=A.FLAG_SORTED_SHADING if args.sorted_shading else 0)
 
         def step():
             ctx.render_into(params, fb.data_ptr(), W, blocking=False)
@@ -380,7 +383,7 @@ def main():
         assert mean > 0 and bool(np.isfinite(image).all()), "framebuffer is empty or not finite"
         value = total * steps / sec_max * 1e-6
         pipe_name = {1: "megakernel", 2: "wavefront"}.get(st["pipeline"], "?")
-        headline = name == HEADLINE and not args.spp
+        headline = name == HEADLINE and not args.spp and not args.sorted_shading
         share = " (tiles index %% %d == 0: one rank's share of C5)" % stride if wl.get("stride", 1) > 1 else ""
         line = {
             "metric": "Msamples/sec, Cornell Box 800x800 spp=400 MIS" if headline else "Msamples/sec, " + name,
@@ -390,8 +393,8 @@ def main():
             "config": {"workload": "scene%02d %dx%d spp=%d depth=50 integrator%d (%s)%s" %
                                    (wl["scene"], W, H, spp, wl["integ"], name, share),
                        "pipeline": pipe_name, "spp_chunks": st["spp_chunks"],
-                       "parallelism": "tiles%%%d" % stride, "seed": 1},
-            "roofline": roofline(name, pipe_name, {} if args.spp else counts, samples, closest, shadow, kms_max, world),
+                       "parallelism": "tiles%%%d" % stride, "seed": 1, "flags_in_effect": st["flags_in_effect"]},
+            "roofline": roofline(name, pipe_name, {} if (args.spp or st["flags_in_effect"]) else counts, samples, closest, shadow, kms_max, world),
             "segments_per_sample": {"closest": round(closest / samples, 4), "shadow": round(shadow / samples, 4)},
             "gather_ms": round(gather_ms, 2), "gather_bytes_per_rank": R.gather_tiles.bytes_sent,
             "image_mean": round(mean, 6),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTR_ABI_VERSION 2 /* 2: rtr_render_stats grew spp_chunks / cancelled */
+#define RTR_ABI_VERSION 3 /* 2: rtr_render_stats grew spp_chunks / cancelled; 3: ... flags_in_effect */
 
 /* ------------------------------------------------------------------------- */
 /* status codes                                                              */
@@ -241,6 +241,12 @@ typedef struct rtr_render_params {
  * (every lane takes the next ray of its wave's blocks as soon as its own is finished) instead of lockstep waves.
  * Same image bit for bit; measured slower on MI355X for every BASELINE scene, kept selectable. */
 #define RTR_FLAG_WF_PERSISTENT 2
+/* Megakernel only: once per bounce the 256 lanes of a workgroup exchange their hits through LDS so that every wave
+ * shades hits of ONE material type (the reference's virtual scatter() call, material.h:31-60, is what diverges).
+ * Exists for the MIS integrator on flat scenes lit by quad lights only (scene 23's kernel); ignored elsewhere.
+ * Same image bit for bit; measured slower on MI355X (4.06 against 6.62 Gsamples/s on scene 23), kept
+ * selectable. */
+#define RTR_FLAG_SORTED_SHADING 4
 
 typedef struct rtr_render_stats {
     uint64_t samples;          /* camera samples finished                               */
@@ -251,6 +257,8 @@ typedef struct rtr_render_stats {
     int32_t pipeline;          /* pipeline that actually ran                            */
     int32_t spp_chunks;        /* partial sums per pixel that were used (params.spp_chunks, or the library's choice for 0) */
     int32_t cancelled;         /* 1: rtr_cancel() stopped this render before its last sample */
+    int32_t flags_in_effect;   /* the RTR_FLAG_* bits of params.flags that selected another kernel than 0 would have */
+    int32_t reserved;
 } rtr_render_stats;
 
 typedef struct rtr_context rtr_context;

@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-RTR_ABI_VERSION = 2
+RTR_ABI_VERSION = 3
 
 # status codes (rtr_status)
 RTR_OK = 0
@@ -26,6 +26,7 @@ INTEGRATOR_PATH, INTEGRATOR_RR, INTEGRATOR_PBR, INTEGRATOR_NEE, INTEGRATOR_MIS =
 PIPELINE_AUTO, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1, 2
 FLAG_REFERENCE_ORDER = 1
 FLAG_WF_PERSISTENT = 2
+FLAG_SORTED_SHADING = 4
 
 NODE_DTYPE = np.dtype([("type", "<i4"), ("a", "<i4"), ("b", "<i4"), ("reserved", "<i4"), ("f", "<f8", (10,))])
 MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("tex", "<i4", (4,)), ("reserved", "<i4", (3,)), ("f", "<f8", (4,))])
@@ -91,7 +92,8 @@ class RenderParamsC(C.Structure):
 class RenderStatsC(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closest_segments", C.c_uint64), ("shadow_segments", C.c_uint64),
                 ("device_ms", C.c_double), ("kernel_launches", C.c_int32), ("pipeline", C.c_int32),
-                ("spp_chunks", C.c_int32), ("cancelled", C.c_int32)]
+                ("spp_chunks", C.c_int32), ("cancelled", C.c_int32), ("flags_in_effect", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 def make_params(width, height, spp, *, integrator=INTEGRATOR_MIS, seed=1, max_depth=50, rr_start_depth=3,

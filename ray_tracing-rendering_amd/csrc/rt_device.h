@@ -40,7 +40,7 @@ typedef double Real;
 enum { RG_OTHER = 0, RG_SETUP = 1, RG_RECTS = 2, RG_SPHERES = 3, RG_GENERIC = 4, RG_TREE = 5, RG_LEAVES = 6, RG_FINISH = 7,
        RG_SH_SETUP = 8, RG_SH_RECTS = 9, RG_SH_SPHERES = 10, RG_SH_GENERIC = 11, RG_SH_TREE = 12, RG_SH_LEAVES = 13,
        RG_MEDIA = 14, RG_MATPREP = 15, RG_SHADE_A = 16, RG_SHADE_B = 17, RG_MISS = 18, RG_REGEN = 19, RG_SHADE_RR = 20,
-       RG_PARK = 21, RG_N = 22 };
+       RG_PARK = 21, RG_BARRIER = 22, RG_EXCHANGE = 23, RG_N = 24 };
 #ifdef RTR_REGION_PROFILE
 __shared__ unsigned long long rt_prof_lds[4 * 2 * RT_PROF_REGIONS + 4 * 2]; /* [wave][cycles | visits][region], then [wave][last, current] */
 RT_DEV void rt_region(int id) {
@@ -2252,17 +2252,20 @@ struct ShadowReq {
  *   RTR_INTEGRATOR_NEE  direct_light_integrator.h:56-95 (emission only at depth 0 / after specular, light sample
  *                       without MIS weight and with the per-channel rescale of :133-139, no fallback)
  *   RTR_INTEGRATOR_PBR  pbr_path_integrator.h:38-68     (emission unweighted, no light sample, no fallback) */
-template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS>
+/* the two parts of shade_a_mis, callable on their own (the material-sorted megakernel runs the first on the lane that
+ * owns the path and the second on the lane that shades it): PART bit 0 = emission, bit 1 = light sample */
+template <int MS = RT_MS_FULL, int INTEG = RTR_INTEGRATOR_MIS, int PART = 3>
 RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, const MatCtx& mc, V3 wo, uint32_t& rng,
                         ShadowReq& rq) {
     RT_REGION(RG_SHADE_A);
     const bool have_lights = sc.n_lights > 0;
     rq.valid = false;
     if (INTEG == RTR_INTEGRATOR_PBR) {
-        ps.L = add(ps.L, mul(ps.thr, mat_emitted(mc, rec))); /* pbr_path_integrator.h:40-41 */
+        if (PART & 1) ps.L = add(ps.L, mul(ps.thr, mat_emitted(mc, rec))); /* pbr_path_integrator.h:40-41 */
         return;
     }
-    if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:56-59 */
+    if (!(PART & 1)) {
+    } else if (INTEG == RTR_INTEGRATOR_NEE) { /* direct_light_integrator.h:56-59 */
         if (ps.depth == 0 || ps.specular_bounce) ps.L = add(ps.L, mul(ps.thr, mat_emitted(mc, rec)));
     } else {
         V3 emitted = mat_emitted(mc, rec);
@@ -2280,7 +2283,7 @@ RT_DEV void shade_a_mis(const DScene& sc, PathState& ps, const Hit& rec, const M
         }
     }
     /* material::is_specular() is never overridden, so NEE runs at every hit */
-    if (have_lights) {
+    if ((PART & 2) && have_lights) {
         const int light_idx = rng_int(rng, 0, sc.n_lights - 1);
         const Real light_select_pdf = 1.0 / sc.n_lights;
         const Real uy = rng_next(rng); /* vec2 u(r(), r()): u.y takes the first draw (g++ order) */

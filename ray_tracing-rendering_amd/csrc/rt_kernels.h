@@ -59,9 +59,39 @@ constexpr int park_words(int integ, int trav) {
                : RT_PARK_WORDS;
 }
 
-template <int INTEG, int TRAV, int MS>
+/* ---- material-sorted shading inside the workgroup ---------------------------------------------------------------
+ * The variant for "every material, QuadLights, flat compiled scene" (scene 23's kernel) regroups the 256 paths of the
+ * tile by the material class of their hit before it shades them.  Without it a wave runs the code of every class
+ * that one of its lanes hit, one after the other, with the lanes whose ray left the scene idle all the while (half of
+ * them on scene 23).  Per bounce: the lane that OWNS a path casts its ray, adds the emission term (it needs the ray
+ * that hit the emitter) and takes a ticket in its class (one LDS atomic per wave and class); after a barrier every lane
+ * knows the class totals, classes are laid out in wave-aligned ranges where 256 slots allow it, the owner writes
+ * (hit point, normal, incoming direction, generator state, material) into its slot; after a second barrier lane i
+ * SHADES slot i -- light sample, BSDF sample, roulette: waves past the last item skip shading altogether -- and writes
+ * throughput / pdf / pending light contribution straight into the owner's parked words and the new direction into the
+ * slot; after a third barrier the owner takes them back.  A path's generator state travels with it and every sum is
+ * formed by the same operands in the same order, so the image is the unsorted kernel's bit for bit
+ * (test_sorted_shading_equals_unsorted).  MEASURED ON SCENE 23: 4 063 against 6 617 Msamples/s unsorted -- the three
+ * barriers cost 16 % of the wave cycles, tickets and exchange 7 %, the owner's emission pass and the second material
+ * fetch another 6 %, and with four classes in four wave-aligned ranges every wave still shades (one class each):
+ * profiles/r03_sorted_regions.txt.  It is therefore NOT what RTR_PIPELINE_AUTO runs; RTR_FLAG_SORTED_SHADING asks
+ * for it. */
+/* which (integrator, traversal, material set) has a sorted instantiation: RTR_FLAG_SORTED_SHADING selects it */
+constexpr bool mega_sortable(int integ, int trav, int ms) {
+    return integ == RTR_INTEGRATOR_MIS && trav == RT_TRAV_FLAT && ms == RT_MS_QUADLIT;
+}
+/* parked words of the sorted variant (the pixel sum lives in the partial-sum buffer itself) + the exchange slot */
+enum { SK_THR = 0, SK_L = 3, SK_PDF = 6, SK_NCLOSEST = 7, SK_NSHADOW = 8, SK_CONTRIB = 9, SK_SWI = 12, SK_STMAX = 15, SK_X = 16,
+       SK_WORDS = 26 };
+enum { SX_P = 0, SX_N = 3, SX_RD = 6, SX_PACK = 9 }; /* slot words: hit point, normal, direction (in: incoming, out: next), packed */
+RT_DEV int material_class(int type) { /* what shades alike */
+    return type == RTR_MAT_LAMBERTIAN ? 0 : (type == RTR_MAT_PBR ? 1 : ((type == RTR_MAT_DIELECTRIC || type == RTR_MAT_METAL) ? 2 : 3));
+}
+
+template <int INTEG, int TRAV, int MS, bool SORT = false>
 __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
     k_mega(const DScene* __restrict__ scp, const RenderK P, const int stack_words) {
+    static_assert(!SORT || mega_sortable(INTEG, TRAV, MS), "no sorted variant of this kernel");
     extern __shared__ int lds_stack[];
     const DScene& sc = *scp;
     const Stack st{lds_stack + threadIdx.x};
@@ -82,7 +112,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
     int s, s_end_;
     chunk_range(P, chunk, s, s_end_);
     const int s_end = s_end_;
-    pk.set3(PK_ACC, mk(0, 0, 0));
+    if (!SORT) pk.set3(PK_ACC, mk(0, 0, 0));
     PathCounters cnt;
     cnt.closest = 0, cnt.shadow = 0;
     uint32_t n_samples = 0;
@@ -90,7 +120,163 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
     uint32_t rng = 1;
     bool fresh = true;
     bool done = !active || s >= s_end;
-    if (TRAV == RT_TRAV_MEDIA) {
+    if (SORT) {
+        /* the class counters live in the traversal-stack words, which a flat scan never touches: one static word more
+         * would round the workgroup's LDS up to the next 512 bytes and cost the third workgroup per CU */
+        int* const s_cnt = lds_stack;
+        const double* const xin = pk.base - threadIdx.x + SK_X * RTR_BLOCK; /* slot q, word k: xin[k * RTR_BLOCK + q] */
+        double* const xw = const_cast<double*>(xin);
+        double* const accp = P.partial + (size_t)cell * 3 * RTR_BLOCK + threadIdx.x; /* this lane's pixel sum */
+        accp[0] = 0.0, accp[RTR_BLOCK] = 0.0, accp[2 * RTR_BLOCK] = 0.0;
+        if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+        auto begin_sample = [&]() { /* renderer.h:73-75 under the per-sample seed */
+            int pi, pj;
+            bool in_region;
+            tile_pixel(P, slot, threadIdx.x, pi, pj, in_region);
+            rng = rtr_sample_seed_inline(P.seed, P.W, pi, pj, s);
+            const Real u = (pi + rng_next(rng)) / (P.W - 1);
+            const Real v = (pj + rng_next(rng)) / (P.H - 1);
+            camera_get_ray(sc.camera, u, v, rng, ps.ro, ps.rd, ps.tm);
+            ps.depth = 0, ps.specular_bounce = false;
+            pk.set3(SK_THR, mk(1.0, 1.0, 1.0));
+            pk.set3(SK_L, mk(0.0, 0.0, 0.0));
+            pk.set(SK_PDF, 0.0);
+        };
+        pk.set(SK_NCLOSEST, 0.0);
+        pk.set(SK_NSHADOW, 0.0);
+        if (!done) begin_sample();
+        __syncthreads();
+        for (;;) {
+            bool pending = false, ended = false, shade_me = false;
+            int cls = 0, ticket = 0;
+            Hit rec;
+            rec.u = 0, rec.v = 0, rec.mat = 0, rec.front = false;
+            RT_REGION(RG_OTHER);
+            if (!done) {
+                pk.set(SK_NCLOSEST, pk.get(SK_NCLOSEST) + 1.0);
+                const bool hit_any = cast_closest<TRAV, false>(sc, ps.ro, ps.rd, ps.tm, rec, rng, st);
+                if (!hit_any) {
+                    RT_REGION(RG_MISS);
+                    pk.set3(SK_L, add(pk.get3(SK_L), miss_radiance<INTEG, MS>(sc, pk.get3(SK_THR), ps.ro, ps.rd, ps.depth,
+                                                                          ps.specular_bounce, pk.get(SK_PDF))));
+                    ended = true;
+                } else { /* the emission term of mis_path_integrator.h:72-94 needs the ray that hit: it stays with the owner */
+                    ps.thr = pk.get3(SK_THR);
+                    ps.L = mk(0.0, 0.0, 0.0);
+                    ps.prev_bsdf_pdf = pk.get(SK_PDF);
+                    const MatCtx mc = mat_prepare<MS>(sc, rec);
+                    ShadowReq none;
+                    shade_a_mis<MS, INTEG, 1>(sc, ps, rec, mc, mk(0, 0, 0), rng, none);
+                    if (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0) pk.set3(SK_L, add(pk.get3(SK_L), ps.L));
+                    shade_me = true;
+                    cls = material_class(mc.type);
+                }
+            }
+            /* tickets: one LDS atomic per wave and class, ranks inside the wave by counting lanes below */
+            RT_REGION(RG_EXCHANGE);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long m = __ballot(shade_me && cls == k);
+                if (m) { /* wave-uniform */
+                    int base = 0;
+                    if ((int)__lane_id() == __builtin_ctzll(m)) base = atomicAdd(&s_cnt[k], __builtin_popcountll(m));
+                    base = __shfl(base, __builtin_ctzll(m), 64);
+                    if (shade_me && cls == k) ticket = base + (int)__builtin_popcountll(m & ((1ull << __lane_id()) - 1ull));
+                }
+            }
+            RT_REGION(RG_BARRIER);
+            if (!__syncthreads_or(!done)) break; /* barrier 1: every ticket is taken; nothing left to do = leave together */
+            RT_REGION(RG_EXCHANGE);
+            const int c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+            int b0 = 0, b1 = (c0 + 63) & ~63, b2 = b1 + ((c1 + 63) & ~63), b3 = b2 + ((c2 + 63) & ~63);
+            if (b3 + c3 > RTR_BLOCK) b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2; /* no room for wave-aligned classes: packed */
+            const int pos = (cls == 0 ? b0 : (cls == 1 ? b1 : (cls == 2 ? b2 : b3))) + ticket;
+            if (shade_me) {
+                xw[(SX_P + 0) * RTR_BLOCK + pos] = rec.p.x, xw[(SX_P + 1) * RTR_BLOCK + pos] = rec.p.y, xw[(SX_P + 2) * RTR_BLOCK + pos] = rec.p.z;
+                xw[(SX_N + 0) * RTR_BLOCK + pos] = rec.n.x, xw[(SX_N + 1) * RTR_BLOCK + pos] = rec.n.y, xw[(SX_N + 2) * RTR_BLOCK + pos] = rec.n.z;
+                xw[(SX_RD + 0) * RTR_BLOCK + pos] = ps.rd.x, xw[(SX_RD + 1) * RTR_BLOCK + pos] = ps.rd.y, xw[(SX_RD + 2) * RTR_BLOCK + pos] = ps.rd.z;
+                const unsigned long long pack = (unsigned long long)rng | ((unsigned long long)(rec.mat & 0xffff) << 32) |
+                                                ((unsigned long long)threadIdx.x << 48) | ((unsigned long long)(rec.front ? 1 : 0) << 56) |
+                                                ((unsigned long long)(ps.depth >= P.rr_start ? 1 : 0) << 57);
+                xw[SX_PACK * RTR_BLOCK + pos] = __longlong_as_double((long long)pack);
+            }
+            RT_REGION(RG_BARRIER);
+            __syncthreads(); /* barrier 2: the slots are filled */
+            RT_REGION(RG_EXCHANGE);
+            if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0; /* everyone has read the totals; the next tickets come after barrier 3 */
+            {
+                const int q = threadIdx.x;
+                const bool mine = (q >= b0 && q < b0 + c0) || (q >= b1 && q < b1 + c1) || (q >= b2 && q < b2 + c2) || (q >= b3 && q < b3 + c3);
+                if (mine) { /* shade slot q: mis_path_integrator.h:96-146 */
+                    const unsigned long long pack = (unsigned long long)__double_as_longlong(xin[SX_PACK * RTR_BLOCK + q]);
+                    Hit h;
+                    h.u = 0, h.v = 0, h.t = 0;
+                    h.p = mk(xin[(SX_P + 0) * RTR_BLOCK + q], xin[(SX_P + 1) * RTR_BLOCK + q], xin[(SX_P + 2) * RTR_BLOCK + q]);
+                    h.n = mk(xin[(SX_N + 0) * RTR_BLOCK + q], xin[(SX_N + 1) * RTR_BLOCK + q], xin[(SX_N + 2) * RTR_BLOCK + q]);
+                    h.mat = (int)((pack >> 32) & 0xffff);
+                    h.front = ((pack >> 56) & 1) != 0;
+                    const int owner = (int)((pack >> 48) & 0xff);
+                    const Park po{pk.base - threadIdx.x + owner}; /* the owner's parked words */
+                    PathState sh;
+                    sh.rd = mk(xin[(SX_RD + 0) * RTR_BLOCK + q], xin[(SX_RD + 1) * RTR_BLOCK + q], xin[(SX_RD + 2) * RTR_BLOCK + q]);
+                    sh.ro = h.p, sh.tm = 0;
+                    sh.thr = po.get3(SK_THR);
+                    sh.L = mk(0.0, 0.0, 0.0);
+                    sh.prev_bsdf_pdf = 0.0;
+                    sh.depth = ((pack >> 57) & 1) ? P.rr_start : P.rr_start - 1; /* only `depth >= rr_start` is read */
+                    sh.specular_bounce = false;
+                    uint32_t r2 = (uint32_t)pack;
+                    const V3 wo = neg(unit(sh.rd));
+                    ShadowReq rq;
+                    const MatCtx mc = mat_prepare<MS>(sc, h);
+                    shade_a_mis<MS, INTEG, 2>(sc, sh, h, mc, wo, r2, rq);
+                    if (rq.valid) {
+                        po.set3(SK_SWI, rq.wi);
+                        po.set(SK_STMAX, rq.tmax);
+                        po.set3(SK_CONTRIB, rq.contrib);
+                    }
+                    const bool go = shade_b_mis<MS, INTEG>(sc, sh, h, mc, wo, r2, P.rr_start);
+                    po.set3(SK_THR, sh.thr);
+                    po.set(SK_PDF, sh.prev_bsdf_pdf);
+                    xw[(SX_RD + 0) * RTR_BLOCK + q] = sh.rd.x, xw[(SX_RD + 1) * RTR_BLOCK + q] = sh.rd.y, xw[(SX_RD + 2) * RTR_BLOCK + q] = sh.rd.z;
+                    const unsigned long long back = (unsigned long long)r2 | ((unsigned long long)(go ? 1 : 0) << 32) |
+                                                    ((unsigned long long)(sh.specular_bounce ? 1 : 0) << 33) |
+                                                    ((unsigned long long)(rq.valid ? 1 : 0) << 34);
+                    xw[SX_PACK * RTR_BLOCK + q] = __longlong_as_double((long long)back);
+                }
+            }
+            RT_REGION(RG_BARRIER);
+            __syncthreads(); /* barrier 3: results are back */
+            RT_REGION(RG_PARK);
+            if (shade_me) {
+                const unsigned long long back = (unsigned long long)__double_as_longlong(xin[SX_PACK * RTR_BLOCK + pos]);
+                rng = (uint32_t)back;
+                ps.ro = mk(xin[(SX_P + 0) * RTR_BLOCK + pos], xin[(SX_P + 1) * RTR_BLOCK + pos], xin[(SX_P + 2) * RTR_BLOCK + pos]);
+                ps.rd = mk(xin[(SX_RD + 0) * RTR_BLOCK + pos], xin[(SX_RD + 1) * RTR_BLOCK + pos], xin[(SX_RD + 2) * RTR_BLOCK + pos]);
+                ps.specular_bounce = ((back >> 33) & 1) != 0;
+                pending = ((back >> 34) & 1) != 0;
+                const bool go = ((back >> 32) & 1) != 0;
+                ended = !go || ++ps.depth >= P.max_depth;
+            }
+            RT_REGION(RG_OTHER);
+            if (pending) { /* mis_path_integrator.h:210-213, origin = the hit point = ps.ro */
+                pk.set(SK_NSHADOW, pk.get(SK_NSHADOW) + 1.0);
+                if (!cast_shadow<TRAV>(sc, ps.ro, pk.get3(SK_SWI), pk.get(SK_STMAX), rng, st))
+                    pk.set3(SK_L, add(pk.get3(SK_L), pk.get3(SK_CONTRIB)));
+            }
+            RT_REGION(RG_REGEN);
+            if (ended) {
+                const V3 L = pk.get3(SK_L);
+                accp[0] += L.x, accp[RTR_BLOCK] += L.y, accp[2 * RTR_BLOCK] += L.z; /* renderer.h:77-78 */
+                ++n_samples;
+                ++s;
+                done = s >= s_end || ((s & 7) == 0 && render_cancelled(P));
+                if (!done) begin_sample();
+            }
+        }
+        cnt.closest = (uint32_t)pk.get(SK_NCLOSEST);
+        cnt.shadow = (uint32_t)pk.get(SK_NSHADOW);
+    } else if (TRAV == RT_TRAV_MEDIA) {
         /* media draw random numbers inside both ray casts: keep the reference's statement order */
         V3 acc = mk(0, 0, 0);
         while (!done) {
@@ -243,11 +429,13 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
         if (v) atomicAdd(&P.stats[RT_PROF_BASE + threadIdx.x], v);
     }
 #endif
-    const V3 acc = pk.get3(PK_ACC);
-    double* out = P.partial + (size_t)cell * 3 * RTR_BLOCK + threadIdx.x;
-    out[0] = acc.x;
-    out[RTR_BLOCK] = acc.y;
-    out[2 * RTR_BLOCK] = acc.z;
+    if (!SORT) { /* (the sorted variant summed into the buffer itself) */
+        const V3 acc = pk.get3(PK_ACC);
+        double* out = P.partial + (size_t)cell * 3 * RTR_BLOCK + threadIdx.x;
+        out[0] = acc.x;
+        out[RTR_BLOCK] = acc.y;
+        out[2 * RTR_BLOCK] = acc.z;
+    }
     unsigned long long a = wave_sum(n_samples), b = wave_sum(cnt.closest), c = wave_sum(cnt.shadow);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&P.stats[0], a);

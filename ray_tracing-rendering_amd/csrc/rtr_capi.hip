@@ -365,7 +365,7 @@ int params_check(rtr_context* c, const rtr_render_params* p) {
     if (p->tile_stride > 1 && (p->tile_first < 0 || p->tile_first >= p->tile_stride))
         return fail(c, RTR_ERR_INVALID, "tile_first must be in [0, tile_stride)");
     if (p->spp_chunks < 0 || p->spp_chunks > p->spp) return fail(c, RTR_ERR_INVALID, "spp_chunks must be in [0, spp]");
-    if (p->flags & ~(RTR_FLAG_REFERENCE_ORDER | RTR_FLAG_WF_PERSISTENT)) return fail(c, RTR_ERR_INVALID, "unknown flag bits");
+    if (p->flags & ~(RTR_FLAG_REFERENCE_ORDER | RTR_FLAG_WF_PERSISTENT | RTR_FLAG_SORTED_SHADING)) return fail(c, RTR_ERR_INVALID, "unknown flag bits");
     if (p->pipeline < RTR_PIPELINE_AUTO || p->pipeline > RTR_PIPELINE_WAVEFRONT)
         return fail(c, RTR_ERR_INVALID, "unknown pipeline");
     return RTR_OK;
@@ -416,20 +416,24 @@ int set_lds(rtr_context* c, K kernel, size_t bytes) {
 }
 
 /* `dry`: only what can fail without touching the stream (the LDS size check / attribute, the occupancy query) */
-int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu) {
+int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu, int flags,
+                int* flags_in_effect = nullptr) {
     MegaLaunch L{};
     /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
     L.trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
     L.integrator = integrator;
     L.stack_words = (int)(stack_bytes(c, L.trav) / (RTR_BLOCK * sizeof(int)));
-    L.lds = stack_bytes(c, L.trav) + (size_t)park_words(integrator, L.trav) * RTR_BLOCK * sizeof(double);
     L.dsc = static_cast<const DScene*>(c->b_dscene.p);
     L.lean = c->lean_materials && L.trav != RT_TRAV_MEDIA && L.trav != RT_TRAV_PROGRAM;
     L.quadlit = c->quad_lights_only && !c->info.needs_uv;
+    /* (the sorted variant packs the material index into 16 bits) */
+    L.sorted = (flags & RTR_FLAG_SORTED_SHADING) && c->n_materials <= 65535 && mega_sortable(integrator, L.trav, L.lean ? RT_MS_LEAN : (L.quadlit ? RT_MS_QUADLIT : RT_MS_FULL));
+    L.lds = stack_bytes(c, L.trav) + (size_t)(L.sorted ? SK_WORDS : park_words(integrator, L.trav)) * RTR_BLOCK * sizeof(double);
     L.stream = c->stream;
     L.P = P;
     L.dry = dry;
     L.blocks_per_cu = blocks_per_cu;
+    if (flags_in_effect && L.sorted) *flags_in_effect |= RTR_FLAG_SORTED_SHADING;
     switch (integrator) {
     case RTR_INTEGRATOR_MIS: return rtr_mega_launch_mis(L, c->err);
     case RTR_INTEGRATOR_RR:
@@ -459,15 +463,14 @@ int auto_chunks(int pipeline, double resident_slots, int n_tiles, int spp) {
     return chunks;
 }
 
-int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, bool dry, int* blocks_per_cu);
 
 /* spp_chunks = 0: the library's choice for this scene, pipeline and number of owned tiles */
-int choose_chunks(rtr_context* c, RenderK P, int integrator, int pipeline, int trav, int spp, int* chunks, int* guided) {
+int choose_chunks(rtr_context* c, RenderK P, int integrator, int pipeline, int trav, int spp, int flags, int* chunks, int* guided) {
     /* workgroups of this kernel variant the chip holds at once (registers / LDS decide: 2-5 per CU) */
     int per_cu = 4;
     P.chunks = 1;
     if (pipeline == RTR_PIPELINE_MEGAKERNEL)
-        if (int rc = launch_mega(c, P, integrator, trav, true, &per_cu)) return rc;
+        if (int rc = launch_mega(c, P, integrator, trav, true, &per_cu, flags)) return rc;
     const double resident = (double)c->n_cus * (per_cu > 0 ? per_cu : 1);
     *chunks = auto_chunks(pipeline, resident, P.n_tiles, spp);
     /* Guided chunks.  With equal chunks a launch ends with part of the chip waiting for the last full-size
@@ -516,7 +519,8 @@ int finish_stats(rtr_context* c) {
                                           "shadow: sphere runs", "shadow: generic scan", "shadow: tree inner nodes",
                                           "shadow: tree leaves", "media steps", "mat_prepare", "shade_a (emission, light sample)",
                                           "shade_b (BSDF sample, roulette)", "miss", "end of sample + regeneration",
-                                          "shade_rr / shade_path", "park path state"};
+                                          "shade_rr / shade_path", "park path state", "sorted shading: barrier waits",
+                                          "sorted shading: tickets + exchange"};
         double total = 0;
         for (int k = 0; k < RG_N; ++k) total += (double)h[RT_PROF_BASE + k];
         std::fprintf(stderr, "[region profile] %.4g wave cycles in all, %llu samples\n", total, h[0]);
@@ -982,7 +986,7 @@ static int render_core(rtr_context* c, const rtr_render_params* p, double* d_rgb
         return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs the compiled traversals only: this graph (or "
                                             "RTR_FLAG_REFERENCE_ORDER) needs the reference-order walk of the megakernel");
     int chunks = p->spp_chunks, guided[3] = {0, 0, 0};
-    if (chunks == 0 && (rc = choose_chunks(c, P, p->integrator, pipeline, trav, p->spp, &chunks, guided))) return rc;
+    if (chunks == 0 && (rc = choose_chunks(c, P, p->integrator, pipeline, trav, p->spp, p->flags, &chunks, guided))) return rc;
     P.n_big = guided[0], P.big_spp = guided[1], P.small_spp = guided[2];
     P.chunks = chunks;
 
@@ -1012,7 +1016,7 @@ static int render_core(rtr_context* c, const rtr_render_params* p, double* d_rgb
     P.cancel = static_cast<const uint32_t*>(c->b_cancel.p);
     P.partial = static_cast<double*>(c->b_partial.p);
     P.done = static_cast<int*>(c->b_done.p);
-    if (pipeline == RTR_PIPELINE_MEGAKERNEL && (rc = launch_mega(c, P, p->integrator, trav, true, nullptr))) return rc;
+    if (pipeline == RTR_PIPELINE_MEGAKERNEL && (rc = launch_mega(c, P, p->integrator, trav, true, nullptr, p->flags))) return rc;
 
     const uint32_t id = c->render_seq.fetch_add(1) + 1; /* rtr_cancel() from now on covers this render */
     P.render_id = id;
@@ -1037,13 +1041,14 @@ static int render_core(rtr_context* c, const rtr_render_params* p, double* d_rgb
         plan.lds = stack_bytes(c, trav);
         plan.trav = trav;
         plan.machine = (p->flags & RTR_FLAG_WF_PERSISTENT) != 0;
+        if (plan.machine) c->stats.flags_in_effect |= RTR_FLAG_WF_PERSISTENT;
         rc = wavefront_render(c->pool, static_cast<const DScene*>(c->b_dscene.p), plan, P, p->integrator, d_rgb, row_stride,
                               tile_done, c->stream, &c->cancelled_upto, &launches, c->err);
         if (rc && rc != RTR_ERR_CANCELLED) return rc;
         if (rc == RTR_ERR_CANCELLED) c->stats.cancelled = 1;
         c->stats.kernel_launches = launches;
     } else {
-        if ((rc = launch_mega(c, P, p->integrator, trav, false, nullptr))) return rc;
+        if ((rc = launch_mega(c, P, p->integrator, trav, false, nullptr, p->flags, &c->stats.flags_in_effect))) return rc;
         ResolveK R{P, d_rgb, (long long)row_stride, tile_done};
         rtr_launch_resolve(R, c->stream);
         HIPCHK(c, hipGetLastError());
@@ -1140,7 +1145,7 @@ int rtr_plan_chunks(rtr_context* c, const rtr_render_params* p) {
     if (P.n_tiles == 0) return 1;
     const int pipeline = p->pipeline == RTR_PIPELINE_AUTO ? RTR_PIPELINE_MEGAKERNEL : p->pipeline;
     int chunks = 1, guided[3];
-    if (int rc = choose_chunks(c, P, p->integrator, pipeline, pick_trav(c, p->flags), p->spp, &chunks, guided)) return rc;
+    if (int rc = choose_chunks(c, P, p->integrator, pipeline, pick_trav(c, p->flags), p->spp, p->flags, &chunks, guided)) return rc;
     return chunks;
 }
 

@@ -47,7 +47,11 @@ int launch_t(const MegaLaunch& L, std::string& err) {
     const int trav = L.trav;
     if (trav == RT_TRAV_FLAT) {
         if (L.lean) RTR_LAUNCH(I, RT_TRAV_FLAT, RT_MS_LEAN);
-        if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_FLAT, FULLQ);
+        if (L.quadlit) {
+            if (mega_sortable(I, RT_TRAV_FLAT, FULLQ) && L.sorted)
+                return launch_one(k_mega<I, RT_TRAV_FLAT, FULLQ, mega_sortable(I, RT_TRAV_FLAT, FULLQ)>, L, err);
+            RTR_LAUNCH(I, RT_TRAV_FLAT, FULLQ);
+        }
         RTR_LAUNCH(I, RT_TRAV_FLAT, RT_MS_FULL);
     }
     if (trav == RT_TRAV_FAST) {

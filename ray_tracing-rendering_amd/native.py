@@ -224,7 +224,7 @@ class Context:
         self._chk(self._L.rtr_get_stats(self._h, C.byref(s)))
         return {"samples": s.samples, "closest_segments": s.closest_segments, "shadow_segments": s.shadow_segments,
                 "device_ms": s.device_ms, "kernel_launches": s.kernel_launches, "pipeline": s.pipeline,
-                "spp_chunks": s.spp_chunks, "cancelled": bool(s.cancelled)}
+                "spp_chunks": s.spp_chunks, "cancelled": bool(s.cancelled), "flags_in_effect": s.flags_in_effect}
 
     def reference_order(self, on):
         """Force the reference-order traversal for rtr_test_hits (renders use params.flags)."""

@@ -48,7 +48,7 @@ def test_sample_seed_matches_oracle():
 def test_struct_sizes_match_headers():
     assert C.sizeof(A.SceneDescC) == 4 * 10 + 8 + 8 * 8 + 192 + 24
     assert C.sizeof(A.RenderParamsC) == 16 * 4
-    assert C.sizeof(A.RenderStatsC) == 3 * 8 + 8 + 4 * 4
+    assert C.sizeof(A.RenderStatsC) == 3 * 8 + 8 + 6 * 4
     assert C.sizeof(rtr.native.SceneInfoC) == 12 * 4
     assert C.sizeof(A.CameraC) == 192
 

@@ -817,6 +817,28 @@ def test_wavefront_persistent_threads_equal_lockstep(ctx, sid, integ):
         assert (st["closest_segments"], st["shadow_segments"]) == (sr["closest_segments"], sr["shadow_segments"])
 
 
+@pytest.mark.parametrize("sid,expect", [(23, True), (7, False), (21, False), (9, False)])
+def test_sorted_shading_equals_unsorted(ctx, sid, expect):
+    """RTR_FLAG_SORTED_SHADING (rt_kernels.h: the lanes of a workgroup exchange their hits through LDS once per bounce
+    so that a wave shades one material type -- the reference's virtual scatter(), material.h:31-60) is a re-scheduling:
+    same image bit for bit and same cast counts as the default kernel, with one running sum and with the library's
+    partial sums, whole image and tile-sharded.  The variant exists for (MIS, flat scene, quad lights only) = scene 23;
+    elsewhere the flag is ignored and stats()["flags_in_effect"] says so."""
+    _upload(ctx, sid)
+    for chunks, stride in ((1, 1), (0, 1), (3, 2)):
+        kw = dict(integrator=4, seed=5, spp_chunks=chunks, tile_first=stride - 1, tile_stride=stride,
+                  pipeline=A.PIPELINE_MEGAKERNEL)
+        ref = ctx.render(A.make_params(112, 80, 24, **kw))
+        sr = ctx.stats()
+        assert sr["flags_in_effect"] == 0
+        out = ctx.render(A.make_params(112, 80, 24, flags=A.FLAG_SORTED_SHADING, **kw))
+        st = ctx.stats()
+        assert (st["flags_in_effect"] == A.FLAG_SORTED_SHADING) == expect
+        assert np.array_equal(_bits(out), _bits(ref)), (chunks, stride)
+        assert (st["samples"], st["closest_segments"], st["shadow_segments"]) == \
+            (sr["samples"], sr["closest_segments"], sr["shadow_segments"])
+
+
 def test_headline_image_at_full_size_and_spp_is_bit_exact(ctx, rtr):
     """BASELINE C2 itself, not a crop: all 640 000 pixels of the Cornell box 800x800 at spp 400 (MIS) from the
     megakernel with one running sum per pixel == the CPU oracle, bit for bit (the oracle is bit-exact against
