@@ -377,7 +377,8 @@ typedef struct rtr_scene_info {
     int32_t inverted_boxes;    /* spheres with a negative radius (hollow glass): sphere::bounding_box (sphere.h:62-66)
                                   then has min > max, the bvh_node boxes built from it do not enclose the sphere,
                                   and which rays still reach it depends on the reference's visiting order */
-    int32_t reserved[1];
+    int32_t top_trees;         /* compiled sub-scenes whose many transformed instances sit in a box tree of their own
+                                  (walked per lane by the megakernel) instead of being scanned one after the other */
 } rtr_scene_info;
 
 /* Host-only: the checks rtr_upload_scene() runs before touching the GPU.  Returns RTR_OK,

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -46,9 +47,17 @@ inline std::vector<FLeaf> build_leaf_records(const CompiledScene& cs, const std:
 constexpr int kLinearMax = 12; /* instances with more references get a box tree */
 constexpr int kLeafMax = 4;
 constexpr int kGroupMax = 8; /* = the most references a leaf link can name (FBvh) */
-constexpr int kMaxInstances = 4096; /* instances of a sub-scene are scanned one after the other (each behind its world
-                                       box): a cost guard, not a correctness limit -- a flat hittable_list of hundreds of
-                                       transformed objects has no cheaper order in the reference either */
+constexpr int kMaxInstances = 1 << 18; /* a cost guard, not a correctness limit (a top tree makes many instances cheap;
+                                          the traversal machine's visit list is still one entry per instance) */
+/* transformed instances from which a sub-scene gets a top tree (FSub::top_root): below, the wave-uniform scan of every
+ * instance behind its world box is as fast or faster than a per-lane walk (tools/time_random.py, one MI355X, top tree
+ * against scan: RR integrator 1.03x at 4 instances, 1.14x at 30, 1.29x at 52, 2.1x at 305; MIS 0.74x at 6, 0.85x at 30,
+ * 1.0x at 52, 1.43x at 305 -- the MIS kernel of a scene without box trees is the flat one with shared reciprocals).
+ * RTR_TOP_MIN, read at every upload, overrides it (sweeps, tests). */
+inline int top_tree_min() {
+    const char* e = std::getenv("RTR_TOP_MIN");
+    return e && *e ? std::atoi(e) : 40;
+}
 constexpr int kMaxTreeDepth = 56; /* bounds the per-lane LDS stack of the box-tree traversal */
 
 struct Box {
@@ -244,6 +253,13 @@ struct Builder {
         return x * y + y * z + z * x;
     }
 
+    /* One unit of a sub-scene's top tree: a transformed instance, or one leaf of the untransformed instance's tree */
+    struct TopItem {
+        Box box;
+        int link;
+        double weight; /* expected cost of entering it, in primitive tests */
+    };
+    std::vector<TopItem>* leaves_out = nullptr; /* build_tree: the leaves it makes, with their boxes */
     /* One unit of the tree build: a single reference, or the references of one small list (a box). */
     struct Item {
         Box box;
@@ -259,7 +275,11 @@ struct Builder {
         int n_refs = 0;
         for (int k = lo; k < hi; ++k) box.grow(items[k].box), n_refs += (int)items[k].members.size();
         const int n = hi - lo;
-        if (n_refs <= kLeafMax || (n == 1 && n_refs <= kGroupMax)) return -1 - (((ref_base + ref_off) << 3) | (n_refs - 1));
+        if (n_refs <= kLeafMax || (n == 1 && n_refs <= kGroupMax)) {
+            const int link = -1 - (((ref_base + ref_off) << 3) | (n_refs - 1));
+            if (leaves_out) leaves_out->push_back(TopItem{box, link, (double)n_refs});
+            return link;
+        }
         max_depth = std::max(max_depth, depth);
         auto centre = [&](int k, int c) { return 0.5 * (items[k].box.lo[c] + items[k].box.hi[c]); };
         Box cb;
@@ -340,6 +360,72 @@ struct Builder {
         return me;
     }
 
+    /* Box tree over items[lo, hi): full-sweep surface-area heuristic over the three centroid orders (the item counts
+     * are instance counts, not primitive counts); balanced median splits once the tree is deep.  A single item is
+     * linked directly: every leaf of this tree is one instance. */
+    int build_top(std::vector<TopItem>& items, int lo, int hi, int depth, int& max_depth, Box& box) {
+        box = Box();
+        for (int k = lo; k < hi; ++k) box.grow(items[k].box);
+        if (hi - lo == 1) return items[lo].link;
+        max_depth = std::max(max_depth, depth);
+        const int n = hi - lo;
+        int best_axis = -1, best_at = -1;
+        double best_cost = INFINITY;
+        auto by_axis = [](int axis) {
+            return [axis](const TopItem& x, const TopItem& y) {
+                return x.box.lo[axis] + x.box.hi[axis] < y.box.lo[axis] + y.box.hi[axis];
+            };
+        };
+        if (depth < 24) {
+            std::vector<double> right_cost(n);
+            for (int axis = 0; axis < 3; ++axis) {
+                std::sort(items.begin() + lo, items.begin() + hi, by_axis(axis));
+                Box acc;
+                double w = 0;
+                for (int k = n - 1; k > 0; --k) {
+                    acc.grow(items[lo + k].box), w += items[lo + k].weight;
+                    right_cost[k] = half_area(acc) * w;
+                }
+                acc = Box(), w = 0;
+                for (int k = 0; k + 1 < n; ++k) { /* split after item k */
+                    acc.grow(items[lo + k].box), w += items[lo + k].weight;
+                    const double cost = half_area(acc) * w + right_cost[k + 1];
+                    if (cost < best_cost) best_cost = cost, best_axis = axis, best_at = k + 1;
+                }
+            }
+        }
+        int mid;
+        if (best_axis >= 0) {
+            std::sort(items.begin() + lo, items.begin() + hi, by_axis(best_axis));
+            mid = lo + best_at;
+        } else {
+            Box cb;
+            for (int k = lo; k < hi; ++k) {
+                const double ctr[3] = {0.5 * (items[k].box.lo[0] + items[k].box.hi[0]), 0.5 * (items[k].box.lo[1] + items[k].box.hi[1]),
+                                       0.5 * (items[k].box.lo[2] + items[k].box.hi[2])};
+                cb.grow(ctr);
+            }
+            int axis = 0;
+            for (int c = 1; c < 3; ++c)
+                if (cb.hi[c] - cb.lo[c] > cb.hi[axis] - cb.lo[axis]) axis = c;
+            mid = (lo + hi) / 2;
+            std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi, by_axis(axis));
+        }
+        const int me = (int)out.bvh.size();
+        out.bvh.push_back(FBvh{});
+        Box bl, br;
+        const int l = build_top(items, lo, mid, depth + 1, max_depth, bl);
+        const int r = build_top(items, mid, hi, depth + 1, max_depth, br);
+        FBvh node{};
+        for (int c = 0; c < 3; ++c) {
+            node.lmin[c] = float_down(bl.lo[c]), node.lmax[c] = float_up(bl.hi[c]);
+            node.rmin[c] = float_down(br.lo[c]), node.rmax[c] = float_up(br.hi[c]);
+        }
+        node.left = l, node.right = r;
+        out.bvh[me] = node;
+        return me;
+    }
+
     int run(int root) { return run(std::vector<int>{root}); }
     /* compile the subtrees under `roots` into one sub-scene; returns its index or -1 (media / too fragmented) */
     int run(const std::vector<int>& roots) {
@@ -355,6 +441,7 @@ struct Builder {
             return -1;
         }
         int stack = 1;
+        std::vector<TopItem> world_leaves; /* of the untransformed instance's tree, if it has one */
         for (size_t ii = inst_base; ii < out.inst.size(); ++ii) {
             FInst& I = out.inst[ii];
             std::vector<PendingRef>& refs = pending[ii - inst_base];
@@ -379,7 +466,11 @@ struct Builder {
                     items[it].box.grow(refs[k].local);
                     items[it].members.push_back(k);
                 }
+                std::vector<TopItem> leaves;
+                leaves_out = I.n_xf == 0 ? &leaves : nullptr;
                 I.bvh_root = build_tree(items, 0, (int)items.size(), 0, I.ref_first, 1, depth, all);
+                leaves_out = nullptr;
+                if (I.n_xf == 0) world_leaves.swap(leaves);
                 std::vector<PendingRef> ordered; /* references in leaf order; a group keeps the reference's visiting order */
                 ordered.reserve(refs.size());
                 for (const Item& it : items)
@@ -420,10 +511,51 @@ struct Builder {
             world.pad();
             for (int c = 0; c < 3; ++c) I.bmin[c] = world.lo[c], I.bmax[c] = world.hi[c];
         }
-        out.stack_words = std::max(out.stack_words, stack);
         FSub sub{};
         sub.inst_first = inst_base;
         sub.n_inst = (int)out.inst.size() - inst_base;
+        sub.top_root = -1, sub.world_inst = -1;
+        {
+            std::vector<TopItem> items;
+            double bound = 0;
+            auto grow_bound = [&bound](const FInst& I) {
+                for (int c = 0; c < 3; ++c) bound = std::max(bound, std::max(std::fabs(I.bmin[c]), std::fabs(I.bmax[c])));
+            };
+            int world = -1;
+            for (size_t ii = inst_base; ii < out.inst.size(); ++ii) {
+                const FInst& I = out.inst[ii];
+                if (I.n_xf == 0) {
+                    world = (int)ii; /* (one per sub-scene: instances are keyed by their chain) */
+                    continue;
+                }
+                TopItem it;
+                for (int c = 0; c < 3; ++c) it.box.lo[c] = I.bmin[c], it.box.hi[c] = I.bmax[c];
+                it.link = -1 - (RT_TOP_INST | (int)ii);
+                it.weight = I.bvh_root >= 0 ? 4.0 + 2.0 * std::log2((double)I.n_ref) : 1.0 + I.n_ref;
+                items.push_back(it);
+                grow_bound(I);
+            }
+            if ((int)items.size() >= top_tree_min() && out.inst.size() < (size_t)RT_TOP_INST && out.ref.size() < (1u << 26)) {
+                sub.world_inst = world;
+                if (world >= 0) {
+                    const FInst& I = out.inst[world];
+                    sub.world_linear = I.bvh_root < 0;
+                    if (I.bvh_root >= 0) { /* its frame is this tree's frame: its leaves are items like the instances,
+                                              one tree separates both (the instance's own tree stays for the kernels
+                                              that scan instances in order) */
+                        items.insert(items.end(), world_leaves.begin(), world_leaves.end());
+                        grow_bound(I);
+                        bound = std::max(bound, (double)I.bound);
+                    }
+                }
+                int depth = 0;
+                Box all;
+                sub.top_root = build_top(items, 0, (int)items.size(), 1, depth, all);
+                sub.top_bound = float_up(bound);
+                stack += depth + 2; /* an instance's own tree is walked on top of its stack */
+            }
+        }
+        out.stack_words = std::max(out.stack_words, stack);
         out.subs.push_back(sub);
         return (int)out.subs.size() - 1;
     }

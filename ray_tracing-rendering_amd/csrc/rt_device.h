@@ -288,6 +288,8 @@ struct DScene {
     const struct FBvh* fbvh;
     const struct FSub* fsub; /* compiled sub-scenes: [0] = whole scene when it has no media */
     int32_t n_finst;         /* instances of sub-scene 0 (0 = none) */
+    int32_t top_root0, world_inst0, world_linear0; /* sub-scene 0's top tree (struct FSub) */
+    float top_bound0;
     int32_t n_fstep;         /* steps of the ray-cast program of a scene with media (0 = none) */
     const struct FStep* fstep;
     int32_t fstep_tail;      /* first step after the last medium */
@@ -389,7 +391,19 @@ struct FLeaf {
  * media around it are unchanged while the bulk of the geometry is traversed order-free. */
 struct FSub {
     int32_t inst_first, n_inst;
+    /* Sub-scenes with many instances (rt_compile.h: kTopTreeMin): one box tree in the sub-scene's own ("world") frame
+     * over the world boxes of the transformed instances, walked PER LANE (trace_top) instead of the wave-uniform scan
+     * of every instance.  Its leaves are single instances (link code RT_TOP_INST | index) and, where the untransformed
+     * instance `world_inst` (whose frame is the world frame) has a box tree, the leaves of that tree: one tree
+     * separates both kinds, a cast is one walk.
+     * top_root < 0: no such tree, the instances are scanned in order. */
+    int32_t top_root;
+    int32_t world_inst;   /* the instance without a transform chain, or -1 */
+    int32_t world_linear; /* 1: `world_inst` has no box tree: scanned (wave-uniformly) before the walk */
+    float top_bound;      /* largest |coordinate| of any box of the walk (see FInst::bound) */
+    int32_t pad[2];
 };
+#define RT_TOP_INST (1 << 30) /* leaf code of a top tree: RT_TOP_INST | instance index */
 #define RT_NODE_COMPILED 11 /* device-only node type: a = sub-scene index */
 /* Ray-cast program of a scene whose constant_media sit under bvh_nodes / hittable_lists only: the
  * reference's visiting order cut into steps -- a medium is a step of its own, every run of
@@ -608,10 +622,17 @@ RT_DEV void wrapper_enter(int type, const double* f, V3& o, V3& d) {
 }
 
 /* defined below (order-free traversal of compiled sub-scenes) */
-template <bool ANY, bool TREES = true, bool WEXIT = ANY>
-__device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
-                                           Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
-                                           const Stack st, const int sp0);
+template <bool ANY, bool TREES = true, bool WEXIT = ANY, bool TOP = false>
+__device__ __forceinline__ bool trace_fast(const DScene& sc, const FSub sub, V3 o, V3 d, Real time, Real tmin, Real& tmax,
+                                           int& hit_ref, int& hit_inst, const Stack st, const int sp0);
+/* sub-scene 0 (the whole scene where it has no media) out of the scene record itself */
+RT_DEV FSub sub_scene0(const DScene& sc) {
+    FSub s;
+    s.inst_first = 0, s.n_inst = sc.n_finst;
+    s.top_root = sc.top_root0, s.world_inst = sc.world_inst0, s.world_linear = sc.world_linear0, s.top_bound = sc.top_bound0;
+    s.pad[0] = s.pad[1] = 0;
+    return s;
+}
 template <bool UV>
 RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref, int inst, Hit& rec);
 
@@ -714,7 +735,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, int root, V3 o, V3 d,
         } else if (MEDIA && type == RT_NODE_COMPILED) { /* a media-free subtree, compiled (see FSub) */
             const FSub sub = ld_const(sc.fsub, n.a);
             int ref, inst;
-            if (trace_fast<false>(sc, sub.inst_first, sub.n_inst, o, d, time, tmin, tmax, ref, inst, st, sp)) {
+            if (trace_fast<false>(sc, sub, o, d, time, tmin, tmax, ref, inst, st, sp)) {
                 ++hits;
                 if (FULL) {
                     if (sc.needs_uv)
@@ -924,7 +945,7 @@ RT_DEV void run_rect_test(Real a0, Real a1, Real b0, Real b1, Real k, int ref, V
  * two moves executed by the lanes that are left, and EXEC is put back: eighteen instructions, the same arithmetic on the
  * same operands in the same order (a SHARED frame produces no NaN, so "not less" and "greater or equal" agree).
  * `tmin` is taken through a scalar pair when it is a literal of the caller (the integrators' 0.001), else per lane. */
-template <int TYPE, bool WEXIT>
+template <int TYPE, bool WEXIT, bool LANE = false>
 RT_DEV void run_rect_test_x(Real a0, Real a1, Real b0, Real b1, Real k, int ref, V3 o, V3 d, const RayDiv& q, Real tmin,
                             Real& tmax, int& hit_ref) {
     const Real ok = TYPE == RTR_NODE_XY_RECT ? o.z : (TYPE == RTR_NODE_XZ_RECT ? o.y : o.x);
@@ -934,9 +955,10 @@ RT_DEV void run_rect_test_x(Real a0, Real a1, Real b0, Real b1, Real k, int ref,
     const Real ob = TYPE == RTR_NODE_XY_RECT ? o.y : o.z, db = TYPE == RTR_NODE_XY_RECT ? d.y : d.z;
     Real n, t, e, u;
     unsigned long long save;
-/* TMIN: constraint of the t_min operand ("s": scalar pair, "v": per lane); BRANCH: the wave-level exit of shadow rays (no
- * lane reaches the plane inside its interval) or nothing */
-#define RT_RECT_X(TMIN, BRANCH)                                                                                          \
+/* TMIN: constraint of the t_min operand ("s": scalar pair, "v": per lane); REC: that of the record's fields and the
+ * reference index ("s" in the wave-uniform scans, "v" where every lane tests a record of its own: LANE); BRANCH: the
+ * wave-level exit of shadow rays (no lane reaches the plane inside its interval) or nothing */
+#define RT_RECT_X(TMIN, REC, BRANCH)                                                                                          \
     asm volatile("v_add_f64 %[n], %[k], -%[ok]\n\t"                                                                     \
                  "v_mul_f64 %[t], %[n], %[rk]\n\t"                                                                       \
                  "v_fma_f64 %[e], -%[dk], %[t], %[n]\n\t"                                                                \
@@ -958,60 +980,65 @@ RT_DEV void run_rect_test_x(Real a0, Real a1, Real b0, Real b1, Real k, int ref,
                  "s_mov_b64 exec, %[save]"                                                                                 \
                  : [n] "=&v"(n), [t] "=&v"(t), [e] "=&v"(e), [u] "=&v"(u), [save] "=&s"(save), [tmax] "+v"(tmax),             \
                    [hit] "+v"(hit_ref)                                                                                     \
-                 : [k] "s"(k), [ok] "v"(ok), [dk] "v"(dk), [rk] "v"(rk), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob),             \
-                   [db] "v"(db), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1), [ref] "s"(ref), [tmin] TMIN(tmin)    \
+                 : [k] REC(k), [ok] "v"(ok), [dk] "v"(dk), [rk] "v"(rk), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob),             \
+                   [db] "v"(db), [a0] REC(a0), [a1] REC(a1), [b0] REC(b0), [b1] REC(b1), [ref] REC(ref), [tmin] TMIN(tmin)    \
                  : "vcc")
-    if (__builtin_constant_p(tmin)) {
-        if (WEXIT)
-            RT_RECT_X("s", "s_cbranch_execz .Lrx%=\n\t");
+    if (LANE) {
+        if (__builtin_constant_p(tmin))
+            RT_RECT_X("s", "v", "");
         else
-            RT_RECT_X("s", "");
+            RT_RECT_X("v", "v", "");
+    } else if (__builtin_constant_p(tmin)) {
+        if (WEXIT)
+            RT_RECT_X("s", "s", "s_cbranch_execz .Lrx%=\n\t");
+        else
+            RT_RECT_X("s", "s", "");
     } else {
         if (WEXIT)
-            RT_RECT_X("v", "s_cbranch_execz .Lrx%=\n\t");
+            RT_RECT_X("v", "s", "s_cbranch_execz .Lrx%=\n\t");
         else
-            RT_RECT_X("v", "");
+            RT_RECT_X("v", "s", "");
     }
 #undef RT_RECT_X
 }
 #ifndef RTR_RECT_ASM
 #define RTR_RECT_ASM 1
 #endif
-template <int TYPE, bool WEXIT, bool SHARED>
+template <int TYPE, bool WEXIT, bool SHARED, bool LANE = false>
 RT_DEV void run_rect(Real a0, Real a1, Real b0, Real b1, Real k, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
                      int& hit_ref) {
     if (RTR_RECT_ASM && SHARED && !q.guard)
-        run_rect_test_x<TYPE, WEXIT>(a0, a1, b0, b1, k, ref, o, d, q, tmin, tmax, hit_ref);
+        run_rect_test_x<TYPE, WEXIT, LANE>(a0, a1, b0, b1, k, ref, o, d, q, tmin, tmax, hit_ref);
     else
         run_rect_test<TYPE, WEXIT, SHARED>(a0, a1, b0, b1, k, ref, o, d, q, tmin, tmax, hit_ref);
 }
-template <int TYPE, bool WEXIT, bool SHARED>
+template <int TYPE, bool WEXIT, bool SHARED, bool LANE = false>
 RT_DEV void run_rects(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
                       int& hit_ref) {
     int k = 0;
     for (; k + 1 < cnt; k += 2, p += 10) { /* two records, one scalar-load round trip */
         const Real f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3], f4 = p[4];
         const Real g0 = p[5], g1 = p[6], g2 = p[7], g3 = p[8], g4 = p[9];
-        run_rect<TYPE, WEXIT, SHARED>(f0, f1, f2, f3, f4, ref + k, o, d, q, tmin, tmax, hit_ref);
-        run_rect<TYPE, WEXIT, SHARED>(g0, g1, g2, g3, g4, ref + k + 1, o, d, q, tmin, tmax, hit_ref);
+        run_rect<TYPE, WEXIT, SHARED, LANE>(f0, f1, f2, f3, f4, ref + k, o, d, q, tmin, tmax, hit_ref);
+        run_rect<TYPE, WEXIT, SHARED, LANE>(g0, g1, g2, g3, g4, ref + k + 1, o, d, q, tmin, tmax, hit_ref);
     }
-    if (k < cnt) run_rect<TYPE, WEXIT, SHARED>(p[0], p[1], p[2], p[3], p[4], ref + k, o, d, q, tmin, tmax, hit_ref);
+    if (k < cnt) run_rect<TYPE, WEXIT, SHARED, LANE>(p[0], p[1], p[2], p[3], p[4], ref + k, o, d, q, tmin, tmax, hit_ref);
 }
 /* A `box` (geometry/box.h:31-47): its six sides, in the order of its hittable_list, from ONE record x0 x1 y0 y1 z0 z1 --
  * one round trip and no per-run overhead for what were three runs of two; the tests are the rectangle tests above, one
  * after the other (hittable_list.h:33-47). */
 #define RT_RUN_BOX 5 /* run type code (types are stored minus RTR_NODE_SPHERE) */
-template <bool WEXIT, bool SHARED>
+template <bool WEXIT, bool SHARED, bool LANE = false>
 RT_DEV void run_boxes(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
                       int& hit_ref) {
     for (int k = 0; k < cnt; ++k, p += 6, ref += 6) {
         const Real x0 = p[0], x1 = p[1], y0 = p[2], y1 = p[3], z0 = p[4], z1 = p[5];
-        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED>(x0, x1, y0, y1, z1, ref, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED>(x0, x1, y0, y1, z0, ref + 1, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED>(x0, x1, z0, z1, y1, ref + 2, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED>(x0, x1, z0, z1, y0, ref + 3, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED>(y0, y1, z0, z1, x1, ref + 4, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED>(y0, y1, z0, z1, x0, ref + 5, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(x0, x1, y0, y1, z1, ref, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(x0, x1, y0, y1, z0, ref + 1, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED, LANE>(x0, x1, z0, z1, y1, ref + 2, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED, LANE>(x0, x1, z0, z1, y0, ref + 3, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED, LANE>(y0, y1, z0, z1, x1, ref + 4, o, d, q, tmin, tmax, hit_ref);
+        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED, LANE>(y0, y1, z0, z1, x0, ref + 5, o, d, q, tmin, tmax, hit_ref);
     }
 }
 template <bool SHARED>
@@ -1033,7 +1060,7 @@ RT_DEV void run_moving_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3
     }
 }
 /* every run of the instance, in visiting order (`t == t_max` is accepted: the later reference wins an exact tie) */
-template <bool WEXIT, bool SHARED>
+template <bool WEXIT, bool SHARED, bool LANE = false>
 RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv& q, Real time, Real tmin, Real& tmax,
                       int& hit_ref) {
     const RT_CONST_AS double* p = as_const(sc.fscan) + I.scan_first;
@@ -1043,16 +1070,16 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
         const int type = RTR_NODE_SPHERE + (int)((runs >> 7) & 7), cnt = (int)(runs & 127);
         RT_REGION(type >= RTR_NODE_XY_RECT ? (WEXIT ? RG_SH_RECTS : RG_RECTS) : (WEXIT ? RG_SH_SPHERES : RG_SPHERES)); /* boxes count as rects */
         if (type == RTR_NODE_XY_RECT) {
-            run_rects<RTR_NODE_XY_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            run_rects<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 5 * cnt;
         } else if (type == RTR_NODE_XZ_RECT) {
-            run_rects<RTR_NODE_XZ_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            run_rects<RTR_NODE_XZ_RECT, WEXIT, SHARED, LANE>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 5 * cnt;
         } else if (type == RTR_NODE_YZ_RECT) {
-            run_rects<RTR_NODE_YZ_RECT, WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            run_rects<RTR_NODE_YZ_RECT, WEXIT, SHARED, LANE>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 5 * cnt;
         } else if (type == RTR_NODE_SPHERE + RT_RUN_BOX) {
-            run_boxes<WEXIT, SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            run_boxes<WEXIT, SHARED, LANE>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 6 * cnt;
             ref += 5 * cnt; /* six references per box */
         } else if (type == RTR_NODE_SPHERE) {
@@ -1184,10 +1211,91 @@ __device__ __forceinline__ bool scan_instance(const DScene& sc, const FInst& I, 
     return false;
 }
 
-template <bool ANY, bool TREES, bool WEXIT>
-__device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_first, const int n_inst, V3 o, V3 d,
-                                           Real time, Real tmin, Real& tmax, int& hit_ref, int& hit_inst,
-                                           const Stack st, const int sp0) {
+/* The per-lane walk of a sub-scene's top tree (struct FSub): inner nodes like scan_instance's, then every lane that
+ * has reached a leaf handles ITS leaf -- references of the untransformed instance in the world frame, or one transformed
+ * instance: its record through vector loads, the ray into its frame, its references (or its own box tree, nested on
+ * the same stack).  Visiting order is whatever the tree gives; exact ties in t are decided by the visiting positions
+ * of the tagged references like everywhere else (RT_TIE_FLAG; rtr_upload_scene tags every pair of coplanar rects of
+ * two instances of such a sub-scene, whatever their order). */
+template <bool ANY>
+__device__ __forceinline__ bool trace_top(const DScene& sc, const FSub sub, V3 o, V3 d, Real time, Real tmin, Real& tmax,
+                                          int& hit_ref, int& hit_inst, int& order, const Stack st, const int sp0) {
+    const BoxRay br = boxray_make(o, d, sub.top_bound);
+    const float tmin_f = float_below(tmin);
+    float tmax_f = float_above(tmax);
+    const bool origin_ok = sc.shared_div != 0 && raydiv_origin_ok(o);
+    int sp = sp0;
+    int node = sub.top_root;
+    while (true) {
+        RT_REGION(ANY ? RG_SH_TREE : RG_TREE);
+        while (node >= 0) {
+            const NodeRegs b = load_node(sc.fbvh, node);
+            float tl, tr;
+            const bool hl = boxray_hit(br, b.lmin, b.lmax, tmin_f, tmax_f, tl);
+            const bool hr = boxray_hit(br, b.rmin, b.rmax, tmin_f, tmax_f, tr);
+            const int cl = b.left, cr = b.right;
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                st.put(sp++, left_first ? cr : cl);
+                node = left_first ? cl : cr;
+            } else if (hl) {
+                node = cl;
+            } else if (hr) {
+                node = cr;
+            } else {
+                node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
+            }
+        }
+        if (node == RT_BVH_DONE) break;
+        RT_REGION(ANY ? RG_SH_LEAVES : RG_LEAVES);
+        const int code = -1 - node;
+        const int before = hit_ref;
+        V3 lo = o, ld = d;
+        int owner = sub.world_inst;
+        FInst I{}; /* what the leaf code below reads of it */
+        I.ref_first = code >> 3, I.n_ref = (code & 7) + 1, I.bvh_root = -1;
+        if (code & RT_TOP_INST) {
+            owner = code & (RT_TOP_INST - 1);
+            I = ld_const(sc.finst, owner);
+            wrapper_enter(I.xf_type[0], I.xf_f[0], lo, ld);
+            if (I.n_xf > 1) wrapper_enter(I.xf_type[1], I.xf_f[1], lo, ld);
+            for (int k = RT_INST_XF_INLINE; k < I.n_xf; ++k) {
+                const FXf x = ld_const(sc.fxf, I.xf_first + k);
+                wrapper_enter(x.type, x.f, lo, ld);
+            }
+        }
+        bool found;
+        if (I.bvh_root >= 0) { /* an instance with a box tree of its own: the same walk one level down, above this one's stack */
+            found = scan_instance<ANY, true, false, false>(sc, I, lo, ld, raydiv_none(), time, tmin, tmax, hit_ref, order, st, sp);
+        } else if (I.flags & RT_INST_RUNS) {
+            /* packed runs (FInst::runs): a `box` is one record and one round trip instead of six leaf records one after
+             * the other; the arithmetic is the flat kernels', divisions through the frame's shared reciprocals where
+             * every lane of the wave that is here may (div_shared) */
+            RayDiv q = raydiv_make(ld, tmin, origin_ok);
+            if (I.flags & RT_INST_SPHERES) raydiv_spheres(q, ld);
+            if (q.fast)
+                scan_runs<false, true, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
+            else
+                scan_runs<false, false, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
+            found = ANY && hit_ref != before;
+        } else {
+            found = leaf_refs<true, false, ANY>(sc, I.ref_first, I.ref_first + I.n_ref, lo, ld, time, tmin, tmax, hit_ref, order);
+        }
+        if (hit_ref != before) hit_inst = owner, tmax_f = float_above(tmax);
+        if (ANY && found) return true;
+        node = sp > sp0 ? st.get(--sp) : RT_BVH_DONE;
+    }
+    return false;
+}
+
+template <bool ANY, bool TREES, bool WEXIT, bool TOP>
+__device__ __forceinline__ bool trace_fast(const DScene& sc, const FSub sub, V3 o, V3 d, Real time, Real tmin, Real& tmax,
+                                           int& hit_ref, int& hit_inst, const Stack st, const int sp0) {
+    /* a sub-scene with a top tree, in a kernel that carries the walk (RT_TRAV_TOP; the others scan its instances in
+     * order like any sub-scene's): only the untransformed instance is scanned here, and only when that has no tree */
+    const bool top = TOP && sub.top_root >= 0;
+    const int inst_first = top ? sub.world_inst : sub.inst_first;
+    const int n_inst = top ? (sub.world_linear ? 1 : 0) : sub.n_inst;
     /* with a handful of instances some lane of the wave enters every one of them, so the boxes
      * would prune nothing at wave level: skip them (and the three divisions of 1/d) */
     const bool use_boxes = n_inst > RT_FAST_NO_BOX_MAX;
@@ -1237,6 +1345,10 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const int inst_firs
         RT_REGION(WEXIT ? RG_SH_SETUP : RG_SETUP);
         if (hit_ref >= I.ref_first) hit_inst = ii;
         if (ANY && found) return true;
+    }
+    if (top) {
+        RT_REGION(WEXIT ? RG_SH_TREE : RG_TREE);
+        if (trace_top<ANY>(sc, sub, o, d, time, tmin, tmax, hit_ref, hit_inst, order, st, sp0) && ANY) return true;
     }
     return hit_ref >= 0;
 }
@@ -1361,6 +1473,7 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
 #define RT_TRAV_FAST 2
 #define RT_TRAV_PROGRAM 3 /* scenes with media: the step program (struct FStep) */
 #define RT_TRAV_FLAT 4    /* compiled scene without box trees and without tie-capable references */
+#define RT_TRAV_TOP 5     /* RT_TRAV_FAST on a scene whose sub-scene 0 has a top tree (FSub::top_root): per-lane instance walk */
 
 /* Run the ray-cast program over [tmin, tmax].  Returns whether anything was hit; then `tmax` is
  * the hit's t and either `med` >= 0 (the step of the medium that scattered the ray) or
@@ -1432,7 +1545,7 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
             int r, i;
             /* ANY = a shadow ray: closest hit all the same (a medium behind needs t_max), but its finite interval
              * lets whole waves leave the rectangle tests early (rect_hit_axes) */
-            const bool h = trace_fast<false, true, ANY>(sc, sub.inst_first, sub.n_inst, o, d, time, lo, t, r, i, st, 0);
+            const bool h = trace_fast<false, true, ANY>(sc, sub, o, d, time, lo, t, r, i, st, 0);
             if (!medium) {
                 if (h) tmax = t, ref = r, inst = i, med = -1, any = true;
             } else if (!h) {
@@ -1452,9 +1565,10 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
 template <int TRAV, bool UV_POSSIBLE = true>
 __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real time, Hit& rec, uint32_t& rng,
                                              const Stack st, Real tmin = 0.001, Real tmax = RT_INF) {
-    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT) {
+    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT || TRAV == RT_TRAV_TOP) {
         int ref, inst;
-        if (!trace_fast<false, TRAV == RT_TRAV_FAST>(sc, 0, sc.n_finst, o, d, time, tmin, tmax, ref, inst, st, 0)) return false;
+        if (!trace_fast<false, TRAV != RT_TRAV_FLAT, false, TRAV == RT_TRAV_TOP>(sc, sub_scene0(sc), o, d, time, tmin, tmax, ref, inst, st, 0))
+            return false;
         if (UV_POSSIBLE && sc.needs_uv)
             fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
         else
@@ -1481,9 +1595,9 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
 }
 template <int TRAV>
 __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real tmax, uint32_t& rng, const Stack st) {
-    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT) {
+    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT || TRAV == RT_TRAV_TOP) {
         int ref, inst;
-        return trace_fast<true, TRAV == RT_TRAV_FAST>(sc, 0, sc.n_finst, o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
+        return trace_fast<true, TRAV != RT_TRAV_FLAT, true, TRAV == RT_TRAV_TOP>(sc, sub_scene0(sc), o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
     }
     if (TRAV == RT_TRAV_PROGRAM) { /* the media behind a blocker still draw */
         int ref, inst, med;

@@ -23,9 +23,9 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hi
     rec.t = 0, rec.p = mk(0, 0, 0), rec.n = mk(0, 0, 0), rec.front = false;
     Real tmax = r.t_max;
     bool h;
-    if (TRAV == RT_TRAV_FAST) {
+    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_TOP) {
         int ref, inst;
-        h = trace_fast<false>(sc, 0, sc.n_finst, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st, 0);
+        h = trace_fast<false, true, false, TRAV == RT_TRAV_TOP>(sc, sub_scene0(sc), ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st, 0);
         if (h) fast_finish<true>(sc, ld3(r.o), ld3(r.d), r.time, tmax, ref, inst, rec);
     } else if (TRAV == RT_TRAV_PROGRAM) {
         h = cast_closest<TRAV>(sc, ld3(r.o), ld3(r.d), r.time, rec, rng, st, r.t_min, tmax);

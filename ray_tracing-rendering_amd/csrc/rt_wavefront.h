@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4)
         if (TRAV == RT_TRAV_PROGRAM)
             run_program<false>(sc, ro, rd, tm, 0.001, t, ref, inst, med, rng, st);
         else
-            trace_fast<false, TRAV == RT_TRAV_FAST>(sc, 0, sc.n_finst, ro, rd, tm, 0.001, t, ref, inst, st, 0);
+            trace_fast<false, TRAV == RT_TRAV_FAST>(sc, sub_scene0(sc), ro, rd, tm, 0.001, t, ref, inst, st, 0);
         wf_extend_store<RICH>(sc, S, P, slot, flags, ro, rd, t, ref, inst, med, rng);
     }
     const unsigned long long c = wave_sum(n_closest);

@@ -398,7 +398,7 @@ int pick_trav(const rtr_context* c, int flags) {
     return c->flat_scene ? RT_TRAV_FLAT : RT_TRAV_FAST;
 }
 size_t stack_bytes(const rtr_context* c, int trav) {
-    const int words = trav == RT_TRAV_FAST || trav == RT_TRAV_FLAT || trav == RT_TRAV_PROGRAM ? c->fast_stack_words
+    const int words = trav == RT_TRAV_FAST || trav == RT_TRAV_FLAT || trav == RT_TRAV_PROGRAM || trav == RT_TRAV_TOP ? c->fast_stack_words
                                                                       : c->info.stack_words + c->walk_extra_words;
     return (size_t)words * RTR_BLOCK * sizeof(int);
 }
@@ -421,6 +421,7 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, b
     MegaLaunch L{};
     /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
     L.trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
+    if (L.trav == RT_TRAV_FAST && c->ds.top_root0 >= 0) L.trav = RT_TRAV_TOP; /* many instances: the per-lane walk (FSub) */
     L.integrator = integrator;
     L.stack_words = (int)(stack_bytes(c, L.trav) / (RTR_BLOCK * sizeof(int)));
     L.dsc = static_cast<const DScene*>(c->b_dscene.p);
@@ -580,6 +581,8 @@ int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* 
         info->fast_stack_words = cs.stack_words;
         info->compiled_subtrees = cs.n_compiled_subtrees;
         info->program_steps = (int32_t)cs.steps.size();
+        info->top_trees = 0;
+        for (const FSub& sub : cs.subs) info->top_trees += sub.top_root >= 0;
     }
     return rc;
 }
@@ -684,6 +687,8 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     if ((rc = upload(c, c->b_fbvh, cs.bvh.data(), sizeof(FBvh) * cs.bvh.size()))) return rc;
     if ((rc = upload(c, c->b_fsub, cs.subs.data(), sizeof(FSub) * cs.subs.size()))) return rc;
     info.program_steps = (int32_t)cs.steps.size();
+    info.top_trees = 0;
+    for (const FSub& sub : cs.subs) info.top_trees += sub.top_root >= 0;
     /* the traversal machine of the wavefront stages always runs a step program: a scene without media is
      * the one-step program "sub-scene 0" */
     std::vector<FStep> dev_steps = cs.steps;
@@ -818,8 +823,11 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
                         for (i = j; i > 0 && cl[i - 1].inst == cl[j - 1].inst; --i) min_after[i - 1] = mn;
                         for (size_t q = i; q < j; ++q) mn = std::min(mn, cl[q].visit);
                     }
+                    /* (a sub-scene with a top tree meets its instances in any order: every such pair then) */
+                    const bool any_order = sub.top_root >= 0;
                     for (size_t q = 0; q < cl.size(); ++q)
-                        if (max_before[q] > cl[q].visit || min_after[q] < cl[q].visit)
+                        if (max_before[q] > cl[q].visit || min_after[q] < cl[q].visit ||
+                            (any_order && (max_before[q] >= 0 || min_after[q] < INT32_MAX)))
                             prims[cl[q].ref].reserved |= RT_TIE_FLAG, any_tie = true;
                 }
                 lo = hi;
@@ -848,6 +856,10 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fbvh = static_cast<const FBvh*>(c->b_fbvh.p);
     d.fsub = static_cast<const FSub*>(c->b_fsub.p);
     d.n_finst = cs.ok ? cs.subs[0].n_inst : 0;
+    d.top_root0 = cs.ok ? cs.subs[0].top_root : -1;
+    d.world_inst0 = cs.ok ? cs.subs[0].world_inst : -1;
+    d.world_linear0 = cs.ok ? cs.subs[0].world_linear : 0;
+    d.top_bound0 = cs.ok ? cs.subs[0].top_bound : 0.0f;
     d.fstep = static_cast<const FStep*>(c->b_fstep.p);
     d.n_fstep = (int32_t)dev_steps.size();
     d.fstep_tail = cs.step_tail;
@@ -1288,6 +1300,7 @@ int rtr_debug_view_get(rtr_context* c, int flags, rtr_debug_view* v, size_t size
     v->n_materials = c->n_materials;
     int trav = pick_trav(c, flags);
     if (trav == RT_TRAV_FLAT) trav = RT_TRAV_FAST;
+    if (trav == RT_TRAV_FAST && c->ds.top_root0 >= 0) trav = RT_TRAV_TOP; /* the unit kernels walk what the megakernel walks */
     v->trav = trav;
     v->stack_bytes = stack_bytes(c, trav);
     return RTR_OK;

@@ -59,6 +59,11 @@ int launch_t(const MegaLaunch& L, std::string& err) {
         if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_FAST, FULLQ);
         RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);
     }
+    if (trav == RT_TRAV_TOP) {
+        if (L.lean) RTR_LAUNCH(I, RT_TRAV_TOP, RT_MS_LEAN);
+        if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_TOP, FULLQ);
+        RTR_LAUNCH(I, RT_TRAV_TOP, RT_MS_FULL);
+    }
     if (trav == RT_TRAV_PROGRAM) {
         if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_PROGRAM, FULLQ);
         RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);
@@ -72,6 +77,7 @@ int launch_t(const MegaLaunch& L, std::string& err) {
 template <int I>
 int launch_n1(const MegaLaunch& L, std::string& err) {
     if (L.trav == RT_TRAV_FAST) RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);
+    if (L.trav == RT_TRAV_TOP) RTR_LAUNCH(I, RT_TRAV_TOP, RT_MS_FULL);
     if (L.trav == RT_TRAV_PROGRAM) RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);
     RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);
 }

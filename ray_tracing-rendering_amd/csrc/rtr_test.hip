@@ -108,6 +108,8 @@ int rtr_test_hits(rtr_context* c, rtr_hit_record* recs, int64_t n) {
     } while (0)
     if (v.trav == RT_TRAV_FAST)
         RTR_HITS(RT_TRAV_FAST);
+    else if (v.trav == RT_TRAV_TOP)
+        RTR_HITS(RT_TRAV_TOP);
     else if (v.trav == RT_TRAV_PROGRAM)
         RTR_HITS(RT_TRAV_PROGRAM);
     else if (v.trav == RT_TRAV_MEDIA)

@@ -31,7 +31,7 @@ class SceneInfoC(C.Structure):
     _fields_ = [("stack_words", C.c_int32), ("has_media", C.c_int32), ("needs_uv", C.c_int32),
                 ("graph_depth", C.c_int32), ("fast_ok", C.c_int32), ("fast_instances", C.c_int32),
                 ("fast_refs", C.c_int32), ("fast_stack_words", C.c_int32), ("compiled_subtrees", C.c_int32),
-                ("program_steps", C.c_int32), ("inverted_boxes", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("program_steps", C.c_int32), ("inverted_boxes", C.c_int32), ("top_trees", C.c_int32)]
 
 
 class RtrError(RuntimeError):
@@ -123,7 +123,7 @@ def validate_scene(scene):
             "graph_depth": info.graph_depth, "fast_ok": bool(info.fast_ok), "fast_instances": info.fast_instances,
             "fast_refs": info.fast_refs, "fast_stack_words": info.fast_stack_words,
             "compiled_subtrees": info.compiled_subtrees, "program_steps": info.program_steps,
-            "inverted_boxes": info.inverted_boxes}
+            "inverted_boxes": info.inverted_boxes, "top_trees": info.top_trees}
 
 
 class Context:

@@ -34,6 +34,9 @@ def test_random_scenes_validate_and_run_on_the_oracle(seed, kw):
     assert info["has_media"] == bool(kw.get("media") or kw.get("moved_media")) and info["inverted_boxes"] == (1 if kw.get("hollow") else 0)
     if not kw.get("media") and not kw.get("hollow") and not kw.get("moved_media"):
         assert info["fast_ok"] and info["fast_refs"] >= 3
+        # dozens of transformed instances sit in a box tree of their own (FSub::top_root): seeds 13 / 19 / 24 / 29
+        # are the cases that put the per-lane instance walk in front of the oracle
+        assert info["top_trees"] == (1 if kw.get("n_objects", 24) >= 200 else 0)  # seed 19: 80 instances
     if kw.get("media") and not kw.get("hollow") and not kw.get("moved_media"):
         assert info["program_steps"] >= 4  # media under lists only: the step program exists
     if kw.get("moved_media"):
@@ -107,3 +110,58 @@ def test_random_scene_renders_equal_the_oracle(ctx, seed, kw):
             worst = max(worst, err)
             assert err <= 1e-12, (tag, err)  # same paths (segment counts equal); libm last bits only
     G.residue("random%02d.renders.worst_rel_l2" % seed, worst, 1e-12)
+
+
+TOP_CASES = [c for c in CASES if not (c[1].get("media") or c[1].get("hollow") or c[1].get("moved_media"))]
+
+
+@pytest.fixture
+def forced_top_tree(monkeypatch):
+    """RTR_TOP_MIN=2 (read at every upload, rt_compile.h): a sub-scene with two transformed instances already gets its
+    top tree, so every media-free random scene goes through the per-lane instance walk (RT_TRAV_TOP)."""
+    monkeypatch.setenv("RTR_TOP_MIN", "2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", TOP_CASES)
+def test_top_tree_walk_equals_the_oracle(ctx, forced_top_tree, seed, kw):
+    """The many-instance path (FSub::top_root, trace_top: one box tree over the transformed instances and the leaves
+    of the untransformed instance's tree, walked per lane, instance records through vector loads, packed runs with
+    per-lane shared reciprocals) against the oracle's in-order scan: hit records bit for bit -- including the exact ties
+    between coplanar rects, which this walk meets in tree order -- and small renders of integrators 1 and 4."""
+    sc = R.random_scene(seed, **kw)
+    assert rtr.native.validate_scene(sc)["top_trees"] == (1 if rtr.native.validate_scene(sc)["fast_instances"] >= 3 else 0)
+    ctx.upload(sc)
+    rays = R.random_rays(seed, 6000)
+    ora = G.oracle_records(sc, "rto_hits", rays)
+    dev = ctx.test_records("hits", rays)
+    h = ora["hit"] == 1
+    assert np.array_equal(dev["hit"], ora["hit"])
+    for f in ("front_face", "material"):
+        assert np.array_equal(dev[f][h], ora[f][h]), f
+    for f in ("t", "p", "n"):
+        assert np.array_equal(_bits(dev[f][h]), _bits(ora[f][h])), f
+    for integ in (1, 4):
+        p = A.make_params(48, 32, 4, integrator=integ, seed=200 + seed, pipeline=A.PIPELINE_MEGAKERNEL)
+        want, wst = G.oracle_render(sc, p)
+        got = ctx.render(p)
+        st = ctx.stats()
+        assert st["closest_segments"] == wst["closest_segments"] and st["shadow_segments"] == wst["shadow_segments"]
+        assert G.rel_l2(got, want) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_top_tree_resolves_ties_across_transform_chains_like_the_reference(ctx, forced_top_tree):
+    """tests/_randscene.cross_instance_tie_scene: faces of translated boxes in the planes of rects the list visits before
+    and after them.  With a top tree the instances are met in tree order, so every such pair carries its visiting
+    position (RT_TIE_FLAG) and the later visit wins, as in the reference's in-order scan."""
+    sc = R.cross_instance_tie_scene()
+    assert rtr.native.validate_scene(sc)["top_trees"] == 1
+    ctx.upload(sc)
+    rays = R.cross_instance_tie_rays()
+    ora = G.oracle_records(sc, "rto_hits", rays)
+    dev = ctx.test_records("hits", rays)
+    h = ora["hit"] == 1
+    assert np.array_equal(dev["hit"], ora["hit"])
+    assert np.array_equal(dev["material"][h], ora["material"][h])
+    assert np.array_equal(_bits(dev["t"][h]), _bits(ora["t"][h]))
