@@ -30,6 +30,8 @@ struct CompiledScene {
     std::vector<FBvh> bvh;
     std::vector<double> scan; /* packed geometry of the linearly scanned instances (FInst::scan_first / run) */
     std::vector<FStep> steps; /* ray-cast program of a scene with media (empty: none could be built) */
+    std::vector<FGuard> guards; /* bvh_node boxes above the guarded primitives (FStep kind 3, RT_GUARD_FLAG references) */
+    std::map<int, std::pair<int, int>> guard_of_ref; /* reference -> (first guard, count): RT_GUARD_FLAG references */
     int step_tail = 0;
     int stack_words = 1;
     bool ok = false;
@@ -83,6 +85,7 @@ struct PendingRef {
     Box local;
     int order; /* position of the primitive's LAST visit in the reference's walk (tie-breaks equal t) */
     int group; /* primitives of one small hittable_list (a `box` = 6 rects) stay together in one tree leaf; -1: none */
+    std::vector<int> guards; /* guard mode, hollow spheres: the bvh_nodes above it, root first */
 };
 
 struct Builder {
@@ -99,6 +102,18 @@ struct Builder {
     int visit_counter = 0;
     int current_group = -1, group_counter = 0;
     bool too_complex = false;
+    /* Guard mode: a graph with hollow spheres (negative radius: inverted bounding box, sphere.h:62-66) and nothing else
+     * that depends on the visiting order.  The reference reaches such a sphere only through rays that pass the boxes of
+     * the bvh_nodes above it within [t_min, closest t so far] (bvh.h:40-50).  If everything sits under ONE transform
+     * chain (the empty one) and is scanned linearly, the scan order IS the reference's visiting order, so the running
+     * t_max at the sphere's reference is the reference's "closest so far" and the box tests can be run right there
+     * (RT_GUARD_FLAG).  Anything else (several instances, too many references for a linear scan, a shared object whose
+     * visits lie on both sides of a hollow sphere) makes run() fail: the caller falls back to the step program. */
+    bool guard_mode = false, guard_fail = false;
+    int hollows_seen = 0;
+    std::vector<int> bvh_stack;
+    std::map<std::pair<int, std::vector<uint64_t>>, int> hollows_at_first_visit;
+    static constexpr int kGuardLinearMax = 256;
 
     static uint64_t bits(double v) {
         uint64_t u;
@@ -159,8 +174,10 @@ struct Builder {
         const rtr_node& n = s->nodes[ix];
         switch (n.type) {
         case RTR_NODE_BVH:
+            bvh_stack.push_back(ix);
             walk(n.a);
             if (n.b != n.a) walk(n.b);
+            bvh_stack.pop_back();
             break;
         case RTR_NODE_LIST: {
             /* a short list of primitives (geometry/box.h: 6 rects) is one object for the box tree */
@@ -187,9 +204,20 @@ struct Builder {
             const int order = visit_counter++;
             auto sk = std::make_pair(ix, full_key());
             auto seen_it = seen.find(sk);
+            const bool hollow = (n.type == RTR_NODE_SPHERE && n.f[3] < 0) || (n.type == RTR_NODE_MOVING_SPHERE && n.f[8] < 0);
             if (seen_it != seen.end()) { /* same primitive, same frame: one test is enough; the later visit wins ties */
                 pending[seen_it->second.first][seen_it->second.second].order = order;
+                /* (scanned at its first visit: a hollow sphere between its visits, or a hollow sphere visited twice
+                 * under different boxes, would see another "closest so far" than the reference) */
+                if (guard_mode && (hollow || hollows_at_first_visit[sk] != hollows_seen)) guard_fail = true;
                 break;
+            }
+            if (guard_mode) {
+                hollows_at_first_visit[sk] = hollows_seen;
+                if (hollow) {
+                    ++hollows_seen;
+                    if (!chain.empty() || n.type != RTR_NODE_SPHERE) guard_fail = true; /* boxes above a transform; f[] full */
+                }
             }
             const std::vector<uint64_t> key = chain_key();
             auto it = inst_of_chain.find(key);
@@ -218,7 +246,8 @@ struct Builder {
                 ii = it->second;
             }
             seen[sk] = {ii - inst_base, (int)pending[ii - inst_base].size()};
-            pending[ii - inst_base].push_back(PendingRef{ix, wrappers, prim_box(n), order, current_group});
+            pending[ii - inst_base].push_back(PendingRef{ix, wrappers, prim_box(n), order, current_group,
+                                                         guard_mode && hollow ? bvh_stack : std::vector<int>()});
         }
         }
     }
@@ -435,6 +464,11 @@ struct Builder {
         const size_t mark[6] = {out.inst.size(), out.xf.size(), out.ref.size(), out.exits.size(), out.bvh.size(), 0};
         inst_base = (int)out.inst.size();
         for (int root : roots) walk(root);
+        if (guard_mode && !too_complex) {
+            size_t n_refs = 0;
+            for (const auto& refs : pending) n_refs += refs.size();
+            if (guard_fail || (int)out.inst.size() - inst_base != 1 || n_refs > (size_t)kGuardLinearMax) too_complex = true;
+        }
         if (too_complex || (int)out.inst.size() == inst_base) { /* undo */
             out.inst.resize(mark[0]), out.xf.resize(mark[1]), out.ref.resize(mark[2]), out.exits.resize(mark[3]);
             out.bvh.resize(mark[4]);
@@ -447,7 +481,7 @@ struct Builder {
             std::vector<PendingRef>& refs = pending[ii - inst_base];
             I.ref_first = (int)out.ref.size();
             I.n_ref = (int)refs.size();
-            if ((int)refs.size() > kLinearMax) {
+            if ((int)refs.size() > kLinearMax && !guard_mode) {
                 int depth = 0;
                 Box all;
                 std::vector<Item> items;
@@ -498,6 +532,14 @@ struct Builder {
                 fr.n_exit = (int)r.wrappers.size();
                 fr.pad = r.order;
                 for (auto it = r.wrappers.rbegin(); it != r.wrappers.rend(); ++it) out.exits.push_back(*it);
+                if (guard_mode && s->nodes[r.node].type == RTR_NODE_SPHERE && s->nodes[r.node].f[3] < 0) {
+                    out.guard_of_ref[(int)out.ref.size()] = {(int)out.guards.size(), (int)r.guards.size()};
+                    for (int g : r.guards) {
+                        FGuard gb;
+                        for (int c = 0; c < 6; ++c) gb.b[c] = s->nodes[g].f[c];
+                        out.guards.push_back(gb);
+                    }
+                }
                 out.ref.push_back(fr);
                 local.grow(r.local);
             }
@@ -612,18 +654,25 @@ struct SubtreeFacts {
  *    with at least kMinCompiled primitives met on the way down from the root is compiled and its
  *    node replaced by RT_NODE_COMPILED in the device copy of the node array. */
 /* `has_media`: the graph holds a constant_medium or an inverted box (order-sensitive parts) */
-inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) {
+/* `hollow`: spheres with a negative radius, no constant_medium: first tried as ONE sub-scene with guarded references
+ * (rtc::Builder::guard_mode), which keeps the scene on the order-free kernels; the step program below otherwise */
+inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media, bool hollow = false) {
     CompiledScene cs;
     cs.dev_nodes.assign(scene->nodes, scene->nodes + scene->n_nodes);
-    if (!has_media) {
+    if (!has_media || hollow) {
         rtc::Builder b(cs);
         b.s = scene;
+        b.guard_mode = hollow;
         cs.ok = b.run(scene->root) == 0;
-        if (!cs.ok) {
-            cs.subs.clear();
-            cs.stack_words = 1;
+        if (cs.ok || !hollow) {
+            if (!cs.ok) {
+                cs.subs.clear();
+                cs.stack_words = 1;
+            }
+            return cs;
         }
-        return cs;
+        cs.subs.clear(), cs.guards.clear(), cs.guard_of_ref.clear();
+        cs.stack_words = 1;
     }
     constexpr int kMinCompiled = 8;
     rtc::SubtreeFacts facts;
@@ -672,20 +721,47 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
      * the graph that holds media; media-free subtrees met on the way are the geometry items */
     {
         std::vector<int> items;
+        std::vector<std::vector<int>> item_wrappers; /* per item (a medium): translate / rotate_y / flip_face above it, outermost first */
+        std::vector<int> item_chain; /* per item: its innermost bvh_node ancestor as an index into `chain` (-1: none) */
+        struct ChainLink {
+            int node, up;
+        };
+        std::vector<ChainLink> chain;
         bool possible = true;
-        std::vector<int> walk_stack{scene->root};
+        std::vector<std::pair<int, int>> walk_stack{{scene->root, -1}};
         while (!walk_stack.empty() && possible) {
-            const int ix = walk_stack.back();
+            const int ix = walk_stack.back().first, up = walk_stack.back().second;
             walk_stack.pop_back();
             const rtr_node& n = scene->nodes[ix];
-            if (!facts.media[ix] || n.type == RTR_NODE_MEDIUM) {
+            const bool hollow = (n.type == RTR_NODE_SPHERE && n.f[3] < 0) || (n.type == RTR_NODE_MOVING_SPHERE && n.f[8] < 0);
+            if (!facts.media[ix] || n.type == RTR_NODE_MEDIUM || hollow) {
                 items.push_back(ix);
+                item_chain.push_back(up);
+                item_wrappers.emplace_back();
+            } else if (n.type == RTR_NODE_TRANSLATE || n.type == RTR_NODE_ROTATE_Y || n.type == RTR_NODE_FLIP_FACE) {
+                /* wrappers straight above ONE medium: a step with a transform chain (FStep::xf_first) */
+                std::vector<int> above;
+                int cur = ix;
+                while (scene->nodes[cur].type == RTR_NODE_TRANSLATE || scene->nodes[cur].type == RTR_NODE_ROTATE_Y ||
+                       scene->nodes[cur].type == RTR_NODE_FLIP_FACE) {
+                    above.push_back(cur);
+                    cur = scene->nodes[cur].a;
+                }
+                if (scene->nodes[cur].type != RTR_NODE_MEDIUM || above.size() > 30) {
+                    possible = false; /* media (or a hollow sphere) deeper under a transform: the reference-order walk */
+                } else {
+                    items.push_back(cur);
+                    item_chain.push_back(up);
+                    item_wrappers.push_back(above);
+                }
             } else if (n.type == RTR_NODE_LIST) {
-                for (int k = n.b - 1; k >= 0; --k) walk_stack.push_back(scene->list_children[n.a + k]);
+                for (int k = n.b - 1; k >= 0; --k) walk_stack.push_back({scene->list_children[n.a + k], up});
             } else if (n.type == RTR_NODE_BVH) {
-                walk_stack.push_back(n.b), walk_stack.push_back(n.a);
+                chain.push_back({ix, up});
+                const int me = (int)chain.size() - 1;
+                walk_stack.push_back({n.b, me}), walk_stack.push_back({n.a, me});
             } else {
-                possible = false; /* a medium under a transform: the reference-order walk handles it */
+                possible = false; /* a medium or a hollow sphere under a transform: the reference-order walk handles it */
             }
         }
         const size_t mark[7] = {cs.inst.size(), cs.xf.size(), cs.ref.size(), cs.exits.size(), cs.bvh.size(), cs.subs.size(),
@@ -705,8 +781,34 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
             st.kind = 0, st.sub = sub;
             cs.steps.push_back(st);
         };
+        const size_t guard_mark = cs.guards.size();
         for (size_t k = 0; k < items.size() && possible; ++k) {
             const rtr_node& n = scene->nodes[items[k]];
+            if (n.type == RTR_NODE_SPHERE || n.type == RTR_NODE_MOVING_SPHERE) {
+                const bool hollow = (n.type == RTR_NODE_SPHERE && n.f[3] < 0) || (n.type == RTR_NODE_MOVING_SPHERE && n.f[8] < 0);
+                if (hollow) { /* a guarded step of its own (FStep kind 3) */
+                    flush();
+                    if (!possible) break;
+                    rtc::Builder b(cs);
+                    b.s = scene;
+                    const int sub = b.run(items[k]);
+                    if (sub < 0) {
+                        possible = false;
+                        break;
+                    }
+                    std::vector<int> above; /* innermost first */
+                    for (int c = item_chain[k]; c >= 0; c = chain[c].up) above.push_back(chain[c].node);
+                    FStep st{};
+                    st.kind = 3, st.sub = sub, st.pad = (int)cs.guards.size(), st.mat = (int)above.size();
+                    for (auto it = above.rbegin(); it != above.rend(); ++it) {
+                        FGuard g;
+                        for (int c = 0; c < 6; ++c) g.b[c] = scene->nodes[*it].f[c];
+                        cs.guards.push_back(g);
+                    }
+                    cs.steps.push_back(st);
+                    continue;
+                }
+            }
             if (n.type != RTR_NODE_MEDIUM) {
                 group.push_back(items[k]);
                 continue;
@@ -715,6 +817,10 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
             if (!possible) break;
             rtc::Builder b(cs);
             b.s = scene;
+            for (int w : item_wrappers[k]) { /* the boundary's references sit under the medium's wrappers */
+                b.wrappers.push_back(w);
+                if (scene->nodes[w].type != RTR_NODE_FLIP_FACE) b.chain.push_back(w);
+            }
             const int sub = b.run(n.a);
             if (sub < 0) {
                 possible = false;
@@ -722,6 +828,19 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
             }
             FStep st{};
             st.kind = 1, st.sub = sub, st.mat = n.b, st.neg_inv_density = n.f[0];
+            st.xf_first = (int)cs.xf.size();
+            for (int w : item_wrappers[k]) {
+                const rtr_node& wn = scene->nodes[w];
+                if (wn.type == RTR_NODE_FLIP_FACE) continue;
+                FXf x{};
+                x.type = wn.type;
+                x.f[0] = wn.f[0], x.f[1] = wn.f[1], x.f[2] = wn.f[2];
+                cs.xf.push_back(x);
+            }
+            st.n_xf = (int)cs.xf.size() - st.xf_first;
+            st.exit_first = (int)cs.exits.size();
+            for (auto it = item_wrappers[k].rbegin(); it != item_wrappers[k].rend(); ++it) cs.exits.push_back(*it);
+            st.n_exit = (int)item_wrappers[k].size();
             const rtr_node& bn = scene->nodes[n.a];
             const FSub& bs = cs.subs[sub];
             if (bn.type == RTR_NODE_SPHERE && bn.f[3] > 0 && bs.n_inst == 1 && cs.inst[bs.inst_first].n_xf == 0 &&
@@ -737,6 +856,7 @@ inline CompiledScene compile_scene(const rtr_scene_desc* scene, bool has_media) 
             cs.stack_words = (int)mark[6];
             cs.steps.clear();
             cs.step_tail = 0;
+            cs.guards.resize(guard_mark);
         }
     }
     return cs;
@@ -774,10 +894,14 @@ inline void rtc::build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>&
             const rtr_node& n = prims[r];
             if (n.reserved & RT_TIE_FLAG) ok = false;
             const bool box = box_at(r);
-            const int type = box ? kBox : n.type;
-            if (runs.empty() || runs.back().first != type || runs.back().second == 127) runs.push_back({type, 0});
+            const bool guarded = (n.reserved & RT_GUARD_FLAG) != 0;
+            const int type = box ? kBox : (guarded ? RTR_NODE_SPHERE + RT_RUN_GUARDED : n.type);
+            if (runs.empty() || runs.back().first != type || runs.back().second == RT_RUN_COUNT_MAX) runs.push_back({type, 0});
             ++runs.back().second;
-            if (box) {
+            if (guarded) { /* centre, radius, first guard and guard count (as the integers' bits): six words */
+                data.insert(data.end(), n.f, n.f + 6);
+                r += 1;
+            } else if (box) {
                 const double rec[6] = {n.f[0], n.f[1], n.f[2], n.f[3], prims[r + 1].f[4], n.f[4]}; /* x0 x1 y0 y1 z0 z1 */
                 data.insert(data.end(), rec, rec + 6);
                 r += 6;
@@ -790,7 +914,7 @@ inline void rtc::build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>&
         if (!ok || (int)runs.size() > RT_INST_RUNS_MAX) continue;
         I.scan_first = (int32_t)cs.scan.size();
         for (size_t k = 0; k < runs.size(); ++k)
-            I.runs |= (uint64_t)((runs[k].first - RTR_NODE_SPHERE) << 7 | runs[k].second) << (10 * k);
+            I.runs |= (uint64_t)((runs[k].first - RTR_NODE_SPHERE) << RT_RUN_COUNT_BITS | runs[k].second) << (RT_RUN_BITS * k);
         cs.scan.insert(cs.scan.end(), data.begin(), data.end());
         I.flags |= RT_INST_RUNS;
     }

@@ -293,6 +293,7 @@ struct DScene {
     int32_t n_fstep;         /* steps of the ray-cast program of a scene with media (0 = none) */
     const struct FStep* fstep;
     int32_t fstep_tail;      /* first step after the last medium */
+    const struct FGuard* fguard; /* boxes of the guarded steps (FStep kind 3) */
     int32_t n_fvisit;        /* visits of the traversal machine's flattened program (rt_machine.h) */
     const struct FVisit* fvisit;
 };
@@ -320,9 +321,10 @@ struct FInst {
      * runs of one primitive type, the geometry of each reference as bare doubles in DScene::fscan from `scan_first` on
      * -- x?_rect: a0 a1 b0 b1 k (aarect.h:31,53,75), sphere: centre radius, moving_sphere: c0 c1 t0 t1 radius.  A
      * run's loop knows its type at compile time and fetches two records per trip through one scalar-load round trip.
-     * `runs` holds up to six runs of ten bits each, first run lowest: (type - RTR_NODE_SPHERE) << 7 | count, 0 ends
-     * the list (one scalar register pair: shifting it out needs no indexed access to this record).  Instances with
-     * more runs than fit, or with tie-capable references, keep the generic loop over fprim (RT_INST_RUNS clear). */
+     * `runs` holds up to eight runs of eight bits each, first run lowest: (type - RTR_NODE_SPHERE) << 5 | count (a
+     * longer run is cut), 0 ends the list (one scalar register pair: shifting it out needs no indexed access to this
+     * record).  Instances with more runs than fit, or with tie-capable references, keep the generic loop over fprim
+     * (RT_INST_RUNS clear).  Type codes beyond the node types: RT_RUN_BOX, RT_RUN_GUARDED. */
     int32_t scan_first;
     int32_t pad;
     uint64_t runs;
@@ -331,7 +333,10 @@ struct FInst {
     int32_t xf_type[2];
     double xf_f[2][3];
 };
-#define RT_INST_RUNS_MAX 6
+#define RT_INST_RUNS_MAX 8
+#define RT_RUN_BITS 8       /* per run: count in the low RT_RUN_COUNT_BITS bits, type code above */
+#define RT_RUN_COUNT_BITS 5
+#define RT_RUN_COUNT_MAX 31
 #define RT_INST_XF_INLINE 2
 #define RT_INST_ROTATED 1 /* a rotate_y in the chain: the direction's x and z differ from the frame above */
 #define RT_INST_SPHERES 2 /* holds sphere / moving_sphere references: the frame needs |d|^2 and its reciprocal */
@@ -418,11 +423,27 @@ struct FSub {
  * wave run the same steps; there is no per-node interpretation left on this path. */
 struct FStep {
     int32_t kind; /* 0: geometry sub-scene `sub`; 1: constant_medium with boundary sub-scene `sub`; 2: constant_medium whose
-                   * boundary is one plain sphere in the world frame, reference `pad` (run_program's short cut; `sub` as for 1) */
+                   * boundary is one plain sphere in the world frame, reference `pad` (run_program's short cut; `sub` as for 1);
+                   * 3: a GUARDED primitive (sub-scene `sub` holds it alone): a sphere with a negative radius -- hollow
+                   * glass, scenes.cpp:903 -- whose bounding box is inverted (sphere.h:62-66), so the boxes of the
+                   * bvh_nodes above it do not enclose it and the reference reaches it only through rays that pass
+                   * every one of those boxes within [t_min, closest t so far] (bvh.h:40-50, aabb.h:31-48): the step
+                   * runs exactly those box tests, `mat` of them from DScene::fguard[`pad`] on, root first */
     int32_t sub;
     int32_t mat;  /* medium: phase function material */
     int32_t pad;
     double neg_inv_density;
+    /* a constant_medium UNDER translate / rotate_y / flip_face wrappers (scenes.cpp:214-217 wraps the boundary; a
+     * wrapped medium is what tests/_randscene.py's moved_media builds): the transform ops of that chain, outermost
+     * first, in DScene::fxf -- constant_medium::hit measures the ray's length in ITS frame (constant_medium.h:84) --
+     * and all wrappers, innermost first, in DScene::fexit for the epilogues on its hit record (hittable.h:58-61,
+     * 142-155, 168).  The boundary sub-scene `sub` carries the same chain in its instances, so it is cast with the
+     * outer ray like every sub-scene. */
+    int32_t xf_first, n_xf;
+    int32_t exit_first, n_exit;
+};
+struct FGuard {
+    double b[6]; /* a bvh_node's box: min, max (geometry/bvh.h:12-31) */
 };
 
 struct Hit { /* geometry/hittable.h:10-23 */
@@ -895,14 +916,33 @@ RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, const RayDiv& q, Real t
  * 1-ulp noise of an UNPADDED box test (faces of `box` objects that touch: the later one is only
  * visited if aabb::hit of its box, entered at exactly that t, survives `t_max <= t_min`). */
 #define RT_TIE_FLAG (1 << 30)
+/* References behind box tests of the reference's bvh_nodes (RT_GUARD_FLAG): a sphere with a negative radius -- hollow
+ * glass, scenes.cpp:903 -- has an inverted bounding box (sphere.h:62-66), the boxes of the bvh_nodes above it do not
+ * enclose it, and bvh_node::hit (bvh.h:40-50) lets a ray through to it only if every one of them is hit within
+ * [t_min, closest t so far] (aabb.h:31-48, with ray.h's 1 / d).  In a sub-scene scanned in the reference's visiting
+ * order the running t_max IS that "closest so far" (rt_compile.h: guard_mode). */
+#define RT_GUARD_FLAG (1 << 29) /* in rtr_node::reserved / FLeaf::tag of a reference, next to RT_TIE_FLAG */
+#define RT_RUN_GUARDED 6        /* run type code: records c r first count */
+RT_DEV bool guard_pass(const DScene& sc, int first, int count, V3 o, V3 d, Real tmin, Real tmax) {
+    const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    bool enter = true;
+    for (int g = 0; g < count; ++g) {
+        const FGuard gb = ld_const(sc.fguard, first + g);
+        enter = enter && aabb_hit(gb.b, o, inv, tmin, tmax);
+    }
+    return enter;
+}
 template <bool TIES = true, bool WAVE_EXIT = false, bool SHARED = false>
 RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, const RayDiv& q, Real time, Real tmin, Real tmax, Real& t,
                          int& order) {
     const rtr_node n = ld_const(sc.fprim, ref);
-    if (!fast_prim_hit<WAVE_EXIT, SHARED>(n, o, d, q, time, tmin, tmax, t)) return false;
     const int tag = n.reserved;
+    if ((tag & RT_GUARD_FLAG) &&
+        !guard_pass(sc, (int)__double_as_longlong(n.f[4]), (int)__double_as_longlong(n.f[5]), o, d, tmin, tmax))
+        return false;
+    if (!fast_prim_hit<WAVE_EXIT, SHARED>(n, o, d, q, time, tmin, tmax, t)) return false;
     if (TIES && (tag & RT_TIE_FLAG)) {
-        const int visit = tag & ~RT_TIE_FLAG;
+        const int visit = tag & ~(RT_TIE_FLAG | RT_GUARD_FLAG);
         if (t == tmax && visit < order) return false;
         order = visit;
     }
@@ -1050,6 +1090,16 @@ RT_DEV void run_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 
     }
 }
 template <bool SHARED>
+RT_DEV void run_guarded_spheres(const DScene& sc, const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q,
+                                Real tmin, Real& tmax, int& hit_ref) {
+    for (int k = 0; k < cnt; ++k, p += 6) {
+        const int first = (int)__double_as_longlong(p[4]), count = (int)__double_as_longlong(p[5]);
+        Real t;
+        if (guard_pass(sc, first, count, o, d, tmin, tmax) && sphere_hit_t<SHARED>(mk(p[0], p[1], p[2]), p[3], o, d, q, tmin, tmax, t))
+            tmax = t, hit_ref = ref + k;
+    }
+}
+template <bool SHARED>
 RT_DEV void run_moving_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real time, Real tmin,
                                Real& tmax, int& hit_ref) {
     for (int k = 0; k < cnt; ++k, p += 9) {
@@ -1066,8 +1116,8 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
     const RT_CONST_AS double* p = as_const(sc.fscan) + I.scan_first;
     int ref = I.ref_first;
 #pragma nounroll
-    for (uint64_t runs = I.runs; runs != 0; runs >>= 10) {
-        const int type = RTR_NODE_SPHERE + (int)((runs >> 7) & 7), cnt = (int)(runs & 127);
+    for (uint64_t runs = I.runs; runs != 0; runs >>= RT_RUN_BITS) {
+        const int type = RTR_NODE_SPHERE + (int)((runs >> RT_RUN_COUNT_BITS) & 7), cnt = (int)(runs & RT_RUN_COUNT_MAX);
         RT_REGION(type >= RTR_NODE_XY_RECT ? (WEXIT ? RG_SH_RECTS : RG_RECTS) : (WEXIT ? RG_SH_SPHERES : RG_SPHERES)); /* boxes count as rects */
         if (type == RTR_NODE_XY_RECT) {
             run_rects<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
@@ -1085,6 +1135,9 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
         } else if (type == RTR_NODE_SPHERE) {
             run_spheres<SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 4 * cnt;
+        } else if (type == RTR_NODE_SPHERE + RT_RUN_GUARDED) {
+            run_guarded_spheres<SHARED>(sc, p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            p += 6 * cnt;
         } else {
             run_moving_spheres<SHARED>(p, cnt, ref, o, d, q, time, tmin, tmax, hit_ref);
             p += 9 * cnt;
@@ -1131,7 +1184,7 @@ RT_DEV bool leaf_refs(const DScene& sc, int r0, int r1, V3 o, V3 d, Real time, R
         }
         if (!hit) continue;
         if (TIES && (L.tag & RT_TIE_FLAG)) { /* see fast_ref_hit */
-            const int visit = L.tag & ~RT_TIE_FLAG;
+            const int visit = L.tag & ~(RT_TIE_FLAG | RT_GUARD_FLAG);
             if (t == tmax && visit < order) continue;
             order = visit;
         }
@@ -1492,12 +1545,20 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
         RT_REGION(RG_MEDIA);
         const FStep step = ld_const(sc.fstep, k);
         /* constant_medium.h:68-103 once both boundary hits exist: clip to the ray's interval, draw, scatter or not */
+        V3 md = d; /* the ray's direction in the medium's own frame */
+        if (step.n_xf > 0) {
+            V3 mo = o;
+            for (int k = 0; k < step.n_xf; ++k) {
+                const FXf x = ld_const(sc.fxf, step.xf_first + k);
+                wrapper_enter(x.type, x.f, mo, md);
+            }
+        }
         auto medium_between = [&](Real t1, Real t2) {
             if (t1 < tmin) t1 = tmin;
             if (t2 > tmax) t2 = tmax;
             if (!(t1 >= t2)) {
                 if (t1 < 0) t1 = 0;
-                const Real ray_length = len(d);
+                const Real ray_length = len(md);
                 const Real distance_inside_boundary = (t2 - t1) * ray_length;
                 const Real hit_distance = step.neg_inv_density * log(rng_next(rng));
                 if (!(hit_distance > distance_inside_boundary)) {
@@ -1535,13 +1596,18 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
             continue;
         }
         const FSub sub = ld_const(sc.fsub, step.sub);
-        const bool medium = step.kind != 0;
+        const bool medium = step.kind == 1;
+        bool enter = true;
+        if (step.kind == 3) { /* the bvh_node::hit calls above the primitive, with the closest t so far */
+            enter = guard_pass(sc, step.pad, step.mat, o, d, tmin, tmax);
+            if (!__any(enter)) continue;
+        }
         Real lo = medium ? -RT_INF : tmin;
         Real t1 = 0;
         const int passes = medium ? 2 : 1;
 #pragma nounroll
         for (int pass = 0; pass < passes; ++pass) {
-            Real t = medium ? RT_INF : tmax;
+            Real t = medium ? RT_INF : (enter ? tmax : -RT_INF); /* (an empty interval: the lane's ray is not let in) */
             int r, i;
             /* ANY = a shadow ray: closest hit all the same (a medium behind needs t_max), but its finite interval
              * lets whole waves leave the rectangle tests early (rect_hit_axes) */
@@ -1561,6 +1627,37 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
     return any;
 }
 
+/* The hit record of a medium step that scattered the ray at t (constant_medium.h:95-101), then the epilogues of the
+ * wrappers the medium sits under, innermost first (fast_finish_long's loop: the k-th transform from the inside saw the ray
+ * after the chain's first n_xf - k ops). */
+__device__ __forceinline__ void medium_finish(const DScene& sc, int med, V3 o, V3 d, Real t, Hit& rec) {
+    const FStep step = ld_const(sc.fstep, med);
+    V3 lo = o, ld = d;
+    for (int k = 0; k < step.n_xf; ++k) {
+        const FXf x = ld_const(sc.fxf, step.xf_first + k);
+        wrapper_enter(x.type, x.f, lo, ld);
+    }
+    rec.t = t;
+    rec.p = add(lo, scl(t, ld));
+    rec.n = mk(1, 0, 0);
+    rec.front = true;
+    rec.mat = step.mat;
+    int level = step.n_xf;
+    for (int e = 0; e < step.n_exit; ++e) {
+        const rtr_node w = ld_const(sc.nodes, as_const(sc.fexit)[step.exit_first + e]);
+        V3 wd = d;
+        if (w.type != RTR_NODE_FLIP_FACE) {
+            V3 wo = o;
+            for (int k = 0; k < level; ++k) {
+                const FXf x = ld_const(sc.fxf, step.xf_first + k);
+                wrapper_enter(x.type, x.f, wo, wd);
+            }
+            --level;
+        }
+        wrapper_epilogue(w, wd, rec);
+    }
+}
+
 /* UV_POSSIBLE = false: the caller's material set has no texture that reads (u,v) (lean / quadlit kernels) */
 template <int TRAV, bool UV_POSSIBLE = true>
 __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real time, Hit& rec, uint32_t& rng,
@@ -1578,12 +1675,8 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
     if (TRAV == RT_TRAV_PROGRAM) {
         int ref, inst, med;
         if (!run_program<false>(sc, o, d, time, tmin, tmax, ref, inst, med, rng, st)) return false;
-        if (med >= 0) { /* constant_medium.h:95-101 */
-            rec.t = tmax;
-            rec.p = add(o, scl(tmax, d));
-            rec.n = mk(1, 0, 0);
-            rec.front = true;
-            rec.mat = as_const(sc.fstep)[med].mat;
+        if (med >= 0) {
+            medium_finish(sc, med, o, d, tmax, rec);
         } else if (UV_POSSIBLE && sc.needs_uv) {
             fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
         } else {

@@ -473,12 +473,8 @@ RT_DEV void wf_hit_record(const DScene& sc, const WfState& S, int slot, V3 o, V3
     const Real t = S.ht[slot];
     const int ref = S.href[slot];
     rec.u = 0, rec.v = 0;
-    if (ref < 0) { /* constant_medium.h:95-101 */
-        rec.t = t;
-        rec.p = add(o, scl(t, d));
-        rec.n = mk(1, 0, 0);
-        rec.front = true;
-        rec.mat = as_const(sc.fstep)[~ref].mat;
+    if (ref < 0) {
+        medium_finish(sc, ~ref, o, d, t, rec);
     } else if (UV_POSSIBLE && sc.needs_uv) {
         fast_finish<true>(sc, o, d, tm, t, ref, S.hinst[slot], rec);
     } else {

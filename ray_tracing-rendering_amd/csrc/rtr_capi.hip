@@ -41,7 +41,7 @@ struct rtr_context {
     rtr_scene_info info{};
     DScene ds{};
     DevBuf b_nodes, b_kids, b_mats, b_tex, b_perlin, b_images, b_imgbytes, b_lights;
-    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan, b_fleaf, b_fmat;
+    DevBuf b_finst, b_fxf, b_fref, b_fexit, b_fbvh, b_dscene, b_fprim, b_fsub, b_fstep, b_fvisit, b_fscan, b_fleaf, b_fmat, b_fguard;
     int fast_stack_words = 1;
     int walk_extra_words = 0; /* stack of a compiled subtree's box tree on top of the walk's own */
     bool lean_materials = false; /* only lambertian / diffuse_light with solid_color textures, only QuadLights */
@@ -72,6 +72,7 @@ struct rtr_context {
     int n_materials = 0;
     int n_cus = 256; /* hipDeviceProp.multiProcessorCount */
     bool machine_ok = false; /* the compiled scene fits the position word of the traversal machine (rt_machine.h) */
+    bool guarded_program = false; /* the step program holds guarded primitives (FStep kind 3) or media under wrappers: not a program of the machine */
 };
 
 namespace {
@@ -390,7 +391,7 @@ std::vector<int> owned_tiles(const rtr_render_params& p, int& tiles_x, int& tile
 /* which traversal a call uses: the compiled scene unless it does not exist or the caller asks
  * for the reference's visiting order */
 int pick_trav(const rtr_context* c, int flags) {
-    if (c->info.has_media || c->info.inverted_boxes)
+    if (c->info.has_media || (c->info.inverted_boxes && !c->info.fast_ok)) /* (hollow spheres as guarded references: compiled) */
         return c->info.program_steps > 0 && !(flags & RTR_FLAG_REFERENCE_ORDER) ? RT_TRAV_PROGRAM
                                                                                                      : RT_TRAV_MEDIA;
     if (!c->info.fast_ok || c->uv_order_dependent || (flags & RTR_FLAG_REFERENCE_ORDER))
@@ -574,7 +575,7 @@ int rtr_validate_scene(const rtr_scene_desc* scene, rtr_scene_info* info, char* 
         std::snprintf(msg, msg_cap, "%s", v.msg.c_str());
     }
     if (rc == RTR_OK && info) {
-        CompiledScene cs = compile_scene(scene, info->has_media != 0 || info->inverted_boxes != 0);
+        CompiledScene cs = compile_scene(scene, info->has_media != 0 || info->inverted_boxes != 0, info->has_media == 0 && info->inverted_boxes != 0);
         info->fast_ok = cs.ok;
         info->fast_instances = (int32_t)cs.inst.size();
         info->fast_refs = (int32_t)cs.ref.size();
@@ -637,7 +638,7 @@ void rtr_destroy(rtr_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_nodes, &c->b_kids,  &c->b_mats,    &c->b_tex,   &c->b_perlin, &c->b_images, &c->b_imgbytes,
                       &c->b_lights, &c->b_tiles, &c->b_partial, &c->b_done, &c->b_stats, &c->b_cancel, &c->b_test, &c->b_stage,
-                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit, &c->b_fscan, &c->b_fleaf, &c->b_fmat};
+                      &c->b_finst, &c->b_fxf, &c->b_fref, &c->b_fexit, &c->b_fbvh, &c->b_dscene, &c->b_fprim, &c->b_fsub, &c->b_fstep, &c->b_fvisit, &c->b_fscan, &c->b_fleaf, &c->b_fmat, &c->b_fguard};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     c->pool.release();
@@ -667,7 +668,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
-    CompiledScene cs = compile_scene(s, info.has_media != 0 || info.inverted_boxes != 0);
+    CompiledScene cs = compile_scene(s, info.has_media != 0 || info.inverted_boxes != 0, info.has_media == 0 && info.inverted_boxes != 0);
     if ((rc = upload(c, c->b_nodes, cs.dev_nodes.data(), sizeof(rtr_node) * cs.dev_nodes.size()))) return rc;
     if ((rc = upload(c, c->b_kids, s->list_children, sizeof(int32_t) * s->n_list_children))) return rc;
     if ((rc = upload(c, c->b_mats, s->materials, sizeof(rtr_material) * s->n_materials))) return rc;
@@ -698,6 +699,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
         dev_steps.push_back(whole);
     }
     if ((rc = upload(c, c->b_fstep, dev_steps.data(), sizeof(FStep) * dev_steps.size()))) return rc;
+    if ((rc = upload(c, c->b_fguard, cs.guards.data(), sizeof(FGuard) * cs.guards.size()))) return rc;
     /* ... flattened into instance visits in execution order */
     std::vector<FVisit> visits;
     for (size_t k = 0; k < dev_steps.size(); ++k) {
@@ -718,6 +720,8 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     }
     if ((rc = upload(c, c->b_fvisit, visits.data(), sizeof(FVisit) * visits.size()))) return rc;
     c->machine_ok = !visits.empty();
+    c->guarded_program = false;
+    for (const FStep& st : dev_steps) c->guarded_program |= st.kind == 3 || st.n_xf > 0 || st.n_exit > 0;
     bool any_tie = false;
     {
         std::vector<rtr_node> prims(cs.ref.size());
@@ -733,6 +737,12 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
             }
             if (!fits) code = RT_EXIT_LONG;
             if (prims[k].type != RTR_NODE_MOVING_SPHERE) std::memcpy(&prims[k].f[9], &code, 8);
+            const auto guard = cs.guard_of_ref.find((int)k);
+            if (guard != cs.guard_of_ref.end()) { /* RT_GUARD_FLAG: first guard and count in a sphere's free words */
+                const long long first = guard->second.first, count = guard->second.second;
+                std::memcpy(&prims[k].f[4], &first, 8), std::memcpy(&prims[k].f[5], &count, 8);
+                prims[k].reserved |= RT_GUARD_FLAG;
+            }
         }
         /* references that can tie exactly in t with another one of their instance (see RT_TIE_FLAG) */
         for (const FInst& I : cs.inst) {
@@ -863,6 +873,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     d.fstep = static_cast<const FStep*>(c->b_fstep.p);
     d.n_fstep = (int32_t)dev_steps.size();
     d.fstep_tail = cs.step_tail;
+    d.fguard = static_cast<const FGuard*>(c->b_fguard.p);
     d.fvisit = static_cast<const FVisit*>(c->b_fvisit.p);
     d.n_fvisit = (int32_t)visits.size();
     d.nodes = static_cast<const rtr_node*>(c->b_nodes.p);
@@ -997,6 +1008,10 @@ static int render_core(rtr_context* c, const rtr_render_params* p, double* d_rgb
     if (pipeline == RTR_PIPELINE_WAVEFRONT && (!c->machine_ok || (trav != RT_TRAV_FLAT && trav != RT_TRAV_FAST && trav != RT_TRAV_PROGRAM)))
         return fail(c, RTR_ERR_UNSUPPORTED, "the wavefront pipeline runs the compiled traversals only: this graph (or "
                                             "RTR_FLAG_REFERENCE_ORDER) needs the reference-order walk of the megakernel");
+    if (pipeline == RTR_PIPELINE_WAVEFRONT && (p->flags & RTR_FLAG_WF_PERSISTENT) && c->guarded_program)
+        return fail(c, RTR_ERR_UNSUPPORTED, "RTR_FLAG_WF_PERSISTENT: the traversal machine does not run step programs with "
+                                            "guarded primitives (hollow spheres under bvh_nodes) or media under transforms; "
+                                            "the lockstep stages do");
     int chunks = p->spp_chunks, guided[3] = {0, 0, 0};
     if (chunks == 0 && (rc = choose_chunks(c, P, p->integrator, pipeline, trav, p->spp, p->flags, &chunks, guided))) return rc;
     P.n_big = guided[0], P.big_spp = guided[1], P.small_spp = guided[2];

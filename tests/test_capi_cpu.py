@@ -72,14 +72,18 @@ def test_validate_golden_scenes(sid, words, media):
 
 
 @pytest.mark.parametrize("sid,inverted", [(30, 1), (33, 1), (34, 1), (39, 1), (40, 1), (23, 0), (1, 0)])
-def test_hollow_spheres_keep_the_reference_walk(sid, inverted):
+def test_hollow_spheres_become_guarded_references(sid, inverted):
     """A sphere with a negative radius (hollow glass) has min > max in sphere::bounding_box, so the
     reference's bvh_node boxes above it do not enclose it and some rays that would hit it are culled:
-    the order-free compiled traversal would see MORE than the reference does (found by rendering
-    every scene id against the reference).  Such scenes keep the reference-order walk."""
+    an order-free traversal of the whole scene would see MORE than the reference does (found by rendering
+    every scene id against the reference).  In the reference's five such scenes everything sits under one transform
+    chain and is few enough for a linear scan in visiting order: the sphere's reference then carries the box tests of
+    the bvh_nodes above it (RT_GUARD_FLAG), taken with the running closest t exactly like bvh_node::hit does, and the
+    scene stays on the compiled kernels.  (Graphs where that does not hold get a step program with a guarded step:
+    tests/test_random_scenes.py, the `hollow` cases.)"""
     info = rtr.native.validate_scene(G.scene(sid))
     assert info["inverted_boxes"] == inverted
-    assert info["fast_ok"] == (inverted == 0)
+    assert info["fast_ok"] and info["program_steps"] == 0 and info["fast_instances"] == 1 or not inverted
 
 
 def test_large_flat_list_compiles():

@@ -39,8 +39,11 @@ def test_random_scenes_validate_and_run_on_the_oracle(seed, kw):
         assert info["top_trees"] == (1 if kw.get("n_objects", 24) >= 200 else 0)  # seed 19: 80 instances
     if kw.get("media") and not kw.get("hollow") and not kw.get("moved_media"):
         assert info["program_steps"] >= 4  # media under lists only: the step program exists
+    if kw.get("hollow"):
+        # transformed boxes next to the hollow sphere: no single scan in visiting order -> a guarded step (FStep kind 3)
+        assert not info["fast_ok"] and info["program_steps"] >= 2
     if kw.get("moved_media"):
-        assert info["program_steps"] == 0  # a medium under a transform: the reference-order walk stays in charge
+        assert info["program_steps"] >= 4  # a medium under translate / rotate_y: a step with a transform chain
     rays = R.random_rays(seed, 500)
     out = G.oracle_records(sc, "rto_hits", rays)
     assert 50 < int(out["hit"].sum()) <= 500
@@ -165,3 +168,17 @@ def test_top_tree_resolves_ties_across_transform_chains_like_the_reference(ctx, 
     assert np.array_equal(dev["hit"], ora["hit"])
     assert np.array_equal(dev["material"][h], ora["material"][h])
     assert np.array_equal(_bits(dev["t"][h]), _bits(ora["t"][h]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", [(16, dict(hollow=True)), (32, dict(moved_media=True))])
+def test_traversal_machine_refuses_what_it_cannot_run(ctx, seed, kw):
+    """Step programs with a guarded step (hollow sphere under bvh_nodes next to transformed boxes) or a medium under
+    translate / rotate_y run on the megakernel and the lockstep wavefront stages (the render test above); the
+    persistent-threads machine (RTR_FLAG_WF_PERSISTENT) has no such step and says so instead of rendering something else."""
+    ctx.upload(R.random_scene(seed, **kw))
+    p = A.make_params(32, 16, 2, integrator=4, seed=1, pipeline=A.PIPELINE_WAVEFRONT, flags=A.FLAG_WF_PERSISTENT)
+    with pytest.raises(rtr.RtrError) as e:
+        ctx.render(p)
+    assert e.value.code == A.ERR_UNSUPPORTED
+    ctx.render(A.make_params(32, 16, 2, integrator=4, seed=1, pipeline=A.PIPELINE_WAVEFRONT))
