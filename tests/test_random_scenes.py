@@ -180,5 +180,5 @@ def test_traversal_machine_refuses_what_it_cannot_run(ctx, seed, kw):
     p = A.make_params(32, 16, 2, integrator=4, seed=1, pipeline=A.PIPELINE_WAVEFRONT, flags=A.FLAG_WF_PERSISTENT)
     with pytest.raises(rtr.RtrError) as e:
         ctx.render(p)
-    assert e.value.code == A.ERR_UNSUPPORTED
+    assert e.value.code == A.RTR_ERR_UNSUPPORTED
     ctx.render(A.make_params(32, 16, 2, integrator=4, seed=1, pipeline=A.PIPELINE_WAVEFRONT))
