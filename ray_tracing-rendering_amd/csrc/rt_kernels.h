@@ -26,9 +26,6 @@
  * 4.36 -> 5.12, scene 1 1.36 -> 1.63 Gsamples/s at 3 instead of 2; the variants with the full light
  * set or the reference-order walk lose 10-30 % there to spills) */
 constexpr int mega_waves(int integ, int trav, int ms) {
-#ifdef RTR_TOP_WAVES /* experiment */
-    if (trav == RT_TRAV_TOP) return RTR_TOP_WAVES;
-#endif
     if (ms == RT_MS_LEAN) return RTR_MEGA_WAVES;
     if (trav == RT_TRAV_PROGRAM) return RTR_PROGRAM_WAVES;
     if (trav == RT_TRAV_MEDIA || trav == RT_TRAV_EXACT) return 2;
