@@ -324,7 +324,7 @@ struct FInst {
      * `runs` holds up to eight runs of eight bits each, first run lowest: (type - RTR_NODE_SPHERE) << 5 | count (a
      * longer run is cut), 0 ends the list (one scalar register pair: shifting it out needs no indexed access to this
      * record).  Instances with more runs than fit, or with tie-capable references, keep the generic loop over fprim
-     * (RT_INST_RUNS clear).  Type codes beyond the node types: RT_RUN_BOX, RT_RUN_GUARDED. */
+     * (RT_INST_RUNS clear).  Type code beyond the node types: RT_RUN_BOX. */
     int32_t scan_first;
     int32_t pad;
     uint64_t runs;
@@ -922,7 +922,6 @@ RT_DEV bool fast_prim_hit(const rtr_node& n, V3 o, V3 d, const RayDiv& q, Real t
  * [t_min, closest t so far] (aabb.h:31-48, with ray.h's 1 / d).  In a sub-scene scanned in the reference's visiting
  * order the running t_max IS that "closest so far" (rt_compile.h: guard_mode). */
 #define RT_GUARD_FLAG (1 << 29) /* in rtr_node::reserved / FLeaf::tag of a reference, next to RT_TIE_FLAG */
-#define RT_RUN_GUARDED 6        /* run type code: records c r first count */
 RT_DEV bool guard_pass(const DScene& sc, int first, int count, V3 o, V3 d, Real tmin, Real tmax) {
     const V3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     bool enter = true;
@@ -937,7 +936,8 @@ RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, const RayDiv& q,
                          int& order) {
     const rtr_node n = ld_const(sc.fprim, ref);
     const int tag = n.reserved;
-    if ((tag & RT_GUARD_FLAG) &&
+    /* (guarded references exist only in scenes that take the kernels with TIES = true: rtr_upload_scene) */
+    if (TIES && (tag & RT_GUARD_FLAG) &&
         !guard_pass(sc, (int)__double_as_longlong(n.f[4]), (int)__double_as_longlong(n.f[5]), o, d, tmin, tmax))
         return false;
     if (!fast_prim_hit<WAVE_EXIT, SHARED>(n, o, d, q, time, tmin, tmax, t)) return false;
@@ -1090,16 +1090,6 @@ RT_DEV void run_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 
     }
 }
 template <bool SHARED>
-RT_DEV void run_guarded_spheres(const DScene& sc, const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q,
-                                Real tmin, Real& tmax, int& hit_ref) {
-    for (int k = 0; k < cnt; ++k, p += 6) {
-        const int first = (int)__double_as_longlong(p[4]), count = (int)__double_as_longlong(p[5]);
-        Real t;
-        if (guard_pass(sc, first, count, o, d, tmin, tmax) && sphere_hit_t<SHARED>(mk(p[0], p[1], p[2]), p[3], o, d, q, tmin, tmax, t))
-            tmax = t, hit_ref = ref + k;
-    }
-}
-template <bool SHARED>
 RT_DEV void run_moving_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real time, Real tmin,
                                Real& tmax, int& hit_ref) {
     for (int k = 0; k < cnt; ++k, p += 9) {
@@ -1135,9 +1125,6 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
         } else if (type == RTR_NODE_SPHERE) {
             run_spheres<SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 4 * cnt;
-        } else if (type == RTR_NODE_SPHERE + RT_RUN_GUARDED) {
-            run_guarded_spheres<SHARED>(sc, p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
-            p += 6 * cnt;
         } else {
             run_moving_spheres<SHARED>(p, cnt, ref, o, d, q, time, tmin, tmax, hit_ref);
             p += 9 * cnt;
@@ -1525,6 +1512,10 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
 #define RT_TRAV_MEDIA 1
 #define RT_TRAV_FAST 2
 #define RT_TRAV_PROGRAM 3 /* scenes with media: the step program (struct FStep) */
+#define RT_TRAV_PROGRAM_EXT 6 /* template value only: RT_TRAV_PROGRAM whose program may hold guarded steps (FStep kind 3) and media
+                                under wrappers (FStep::n_xf); compiled into the plain program kernels that code cost scenes 9 / 22
+                                7 % / 4 %, so the megakernel has both and picks per scene; the other kernels take this one */
+constexpr bool rt_is_program(int trav) { return trav == RT_TRAV_PROGRAM || trav == RT_TRAV_PROGRAM_EXT; }
 #define RT_TRAV_FLAT 4    /* compiled scene without box trees and without tie-capable references */
 #define RT_TRAV_TOP 5     /* RT_TRAV_FAST on a scene whose sub-scene 0 has a top tree (FSub::top_root): per-lane instance walk */
 
@@ -1532,7 +1523,7 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
  * the hit's t and either `med` >= 0 (the step of the medium that scattered the ray) or
  * (`ref`, `inst`) name the surface.  One trace_fast call site serves the geometry steps and both
  * boundary casts of a medium (constant_medium.h:62-66). */
-template <bool ANY>
+template <bool ANY, bool EXT = true>
 __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real time, Real tmin, Real& tmax, int& ref,
                                             int& inst, int& med, uint32_t& rng, const Stack st) {
     ref = -1, inst = -1, med = -1;
@@ -1546,7 +1537,7 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
         const FStep step = ld_const(sc.fstep, k);
         /* constant_medium.h:68-103 once both boundary hits exist: clip to the ray's interval, draw, scatter or not */
         V3 md = d; /* the ray's direction in the medium's own frame */
-        if (step.n_xf > 0) {
+        if (EXT && step.n_xf > 0) {
             V3 mo = o;
             for (int k = 0; k < step.n_xf; ++k) {
                 const FXf x = ld_const(sc.fxf, step.xf_first + k);
@@ -1598,7 +1589,7 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
         const FSub sub = ld_const(sc.fsub, step.sub);
         const bool medium = step.kind == 1;
         bool enter = true;
-        if (step.kind == 3) { /* the bvh_node::hit calls above the primitive, with the closest t so far */
+        if (EXT && step.kind == 3) { /* the bvh_node::hit calls above the primitive, with the closest t so far */
             enter = guard_pass(sc, step.pad, step.mat, o, d, tmin, tmax);
             if (!__any(enter)) continue;
         }
@@ -1607,7 +1598,7 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
         const int passes = medium ? 2 : 1;
 #pragma nounroll
         for (int pass = 0; pass < passes; ++pass) {
-            Real t = medium ? RT_INF : (enter ? tmax : -RT_INF); /* (an empty interval: the lane's ray is not let in) */
+            Real t = medium ? RT_INF : (!EXT || enter ? tmax : -RT_INF); /* (an empty interval: the lane's ray is not let in) */
             int r, i;
             /* ANY = a shadow ray: closest hit all the same (a medium behind needs t_max), but its finite interval
              * lets whole waves leave the rectangle tests early (rect_hit_axes) */
@@ -1630,7 +1621,16 @@ __device__ __forceinline__ bool run_program(const DScene& sc, V3 o, V3 d, Real t
 /* The hit record of a medium step that scattered the ray at t (constant_medium.h:95-101), then the epilogues of the
  * wrappers the medium sits under, innermost first (fast_finish_long's loop: the k-th transform from the inside saw the ray
  * after the chain's first n_xf - k ops). */
+template <bool EXT = true>
 __device__ __forceinline__ void medium_finish(const DScene& sc, int med, V3 o, V3 d, Real t, Hit& rec) {
+    if (!EXT) {
+        rec.t = t;
+        rec.p = add(o, scl(t, d));
+        rec.n = mk(1, 0, 0);
+        rec.front = true;
+        rec.mat = as_const(sc.fstep)[med].mat;
+        return;
+    }
     const FStep step = ld_const(sc.fstep, med);
     V3 lo = o, ld = d;
     for (int k = 0; k < step.n_xf; ++k) {
@@ -1672,11 +1672,11 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
             fast_finish<false>(sc, o, d, time, tmax, ref, inst, rec);
         return true;
     }
-    if (TRAV == RT_TRAV_PROGRAM) {
+    if (rt_is_program(TRAV)) {
         int ref, inst, med;
-        if (!run_program<false>(sc, o, d, time, tmin, tmax, ref, inst, med, rng, st)) return false;
+        if (!run_program<false, TRAV == RT_TRAV_PROGRAM_EXT>(sc, o, d, time, tmin, tmax, ref, inst, med, rng, st)) return false;
         if (med >= 0) {
-            medium_finish(sc, med, o, d, tmax, rec);
+            medium_finish<TRAV == RT_TRAV_PROGRAM_EXT>(sc, med, o, d, tmax, rec);
         } else if (UV_POSSIBLE && sc.needs_uv) {
             fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
         } else {
@@ -1692,9 +1692,9 @@ __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real t
         int ref, inst;
         return trace_fast<true, TRAV != RT_TRAV_FLAT, true, TRAV == RT_TRAV_TOP>(sc, sub_scene0(sc), o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
     }
-    if (TRAV == RT_TRAV_PROGRAM) { /* the media behind a blocker still draw */
+    if (rt_is_program(TRAV)) { /* the media behind a blocker still draw */
         int ref, inst, med;
-        return run_program<true>(sc, o, d, 0.0, 0.001, tmax, ref, inst, med, rng, st);
+        return run_program<true, TRAV == RT_TRAV_PROGRAM_EXT>(sc, o, d, 0.0, 0.001, tmax, ref, inst, med, rng, st);
     }
     Hit dummy;
     return traverse<false, TRAV == RT_TRAV_MEDIA>(sc, sc.root, o, d, 0.0, 0.001, tmax, dummy, rng, st, 0);

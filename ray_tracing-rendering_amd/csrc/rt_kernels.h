@@ -27,7 +27,7 @@
  * set or the reference-order walk lose 10-30 % there to spills) */
 constexpr int mega_waves(int integ, int trav, int ms) {
     if (ms == RT_MS_LEAN) return RTR_MEGA_WAVES;
-    if (trav == RT_TRAV_PROGRAM) return RTR_PROGRAM_WAVES;
+    if (rt_is_program(trav)) return RTR_PROGRAM_WAVES;
     if (trav == RT_TRAV_MEDIA || trav == RT_TRAV_EXACT) return 2;
     if (ms == RT_MS_QUADLIT) return 3;
     if (integ == RTR_INTEGRATOR_RR || integ == RTR_INTEGRATOR_PATH) return 3;
@@ -54,7 +54,7 @@ enum { PK_THR = 0, PK_L = 3, PK_ACC = 6, PK_PDF = 9, PK_NCLOSEST = 10, PK_NSHADO
  * BSDF sample (MIS-type integrators on scenes without media); fewer words = more workgroups per CU where
  * LDS, not registers, is the limit (the lean RR kernel: 92 VGPRs) */
 constexpr int park_words(int integ, int trav) {
-    return (integ == RTR_INTEGRATOR_RR || integ == RTR_INTEGRATOR_PATH || trav == RT_TRAV_PROGRAM || trav == RT_TRAV_MEDIA)
+    return (integ == RTR_INTEGRATOR_RR || integ == RTR_INTEGRATOR_PATH || rt_is_program(trav) || trav == RT_TRAV_MEDIA)
                ? 12
                : RT_PARK_WORDS;
 }
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, mega_waves(INTEG, TRAV, MS))
                         ShadowReq rq;
                         MatCtx mc = mat_prepare<MS>(sc, rec);
                         shade_a_mis<MS, INTEG>(sc, ps, rec, mc, wo, rng, rq);
-                        if (TRAV == RT_TRAV_PROGRAM) {
+                        if (rt_is_program(TRAV)) {
                             /* media draw inside the shadow cast: it keeps its place between the light
                              * sample and the BSDF sample (mis_path_integrator.h:96-106) */
                             if (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0) {

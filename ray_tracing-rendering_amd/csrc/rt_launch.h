@@ -16,6 +16,7 @@ struct MegaLaunch {
     int integrator, trav;
     bool lean, quadlit; /* material / light set of the scene (rtr_upload_scene) */
     bool sorted;        /* RTR_FLAG_SORTED_SHADING and a sorted instantiation exists for this launch (rt_kernels.h) */
+    bool program_ext;   /* RT_TRAV_PROGRAM: the program holds guarded steps or media under wrappers (RT_TRAV_PROGRAM_EXT kernels) */
     size_t lds;         /* traversal stack + parked path state, bytes per workgroup */
     int stack_words;
     hipStream_t stream;

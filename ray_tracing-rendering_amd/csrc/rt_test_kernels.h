@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(RTR_BLOCK) k_test_hits(const DScene sc, rtr_hi
         int ref, inst;
         h = trace_fast<false, true, false, TRAV == RT_TRAV_TOP>(sc, sub_scene0(sc), ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, ref, inst, st, 0);
         if (h) fast_finish<true>(sc, ld3(r.o), ld3(r.d), r.time, tmax, ref, inst, rec);
-    } else if (TRAV == RT_TRAV_PROGRAM) {
+    } else if (rt_is_program(TRAV)) {
         h = cast_closest<TRAV>(sc, ld3(r.o), ld3(r.d), r.time, rec, rng, st, r.t_min, tmax);
     } else {
         h = traverse<true, TRAV == RT_TRAV_MEDIA>(sc, sc.root, ld3(r.o), ld3(r.d), r.time, r.t_min, tmax, rec, rng, st, 0);

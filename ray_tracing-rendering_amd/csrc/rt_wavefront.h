@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4)
         ++n_closest;
         Real t = RT_INF;
         int ref = -1, inst = -1, med = -1;
-        if (TRAV == RT_TRAV_PROGRAM)
+        if (rt_is_program(TRAV))
             run_program<false>(sc, ro, rd, tm, 0.001, t, ref, inst, med, rng, st);
         else
             trace_fast<false, TRAV == RT_TRAV_FAST>(sc, sub_scene0(sc), ro, rd, tm, 0.001, t, ref, inst, st, 0);
@@ -456,10 +456,10 @@ __global__ void __launch_bounds__(RTR_BLOCK, 4)
         if (!(flags & WF_SHADOW)) continue;
         S.flags[slot] = flags & ~WF_SHADOW;
         ++n_shadow;
-        uint32_t rng = TRAV == RT_TRAV_PROGRAM ? S.rng[slot] : 1u;
+        uint32_t rng = rt_is_program(TRAV) ? S.rng[slot] : 1u;
         const bool blocked = cast_shadow<TRAV>(sc, ldv(S.sox, S.soy, S.soz, slot), ldv(S.swx, S.swy, S.swz, slot),
                                                S.stmax[slot], rng, st);
-        if (TRAV == RT_TRAV_PROGRAM) S.rng[slot] = rng;
+        if (rt_is_program(TRAV)) S.rng[slot] = rng;
         if (!blocked) stv(S.lx, S.ly, S.lz, slot, add(ldv(S.lx, S.ly, S.lz, slot), ldv(S.scx, S.scy, S.scz, slot)));
     }
     const unsigned long long c = wave_sum(n_shadow);
@@ -689,8 +689,8 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
         if ((rc = wf_lds_attr(wf_extend<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend<false>, plan.lds, err)) ||
             (rc = wf_lds_attr(wf_connect<true>, plan.lds, err)) || (rc = wf_lds_attr(wf_connect<false>, plan.lds, err)) ||
             (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_FAST, true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_FAST, false>, plan.lds, err)) ||
-            (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_PROGRAM, true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_PROGRAM, false>, plan.lds, err)) ||
-            (rc = wf_lds_attr(wf_connect_ls<RT_TRAV_FAST>, plan.lds, err)) || (rc = wf_lds_attr(wf_connect_ls<RT_TRAV_PROGRAM>, plan.lds, err)))
+            (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_PROGRAM_EXT, true>, plan.lds, err)) || (rc = wf_lds_attr(wf_extend_ls<RT_TRAV_PROGRAM_EXT, false>, plan.lds, err)) ||
+            (rc = wf_lds_attr(wf_connect_ls<RT_TRAV_FAST>, plan.lds, err)) || (rc = wf_lds_attr(wf_connect_ls<RT_TRAV_PROGRAM_EXT>, plan.lds, err)))
             return rc;
     if (plan.lds > 160 * 1024) return wf_lds_attr(wf_extend<true>, plan.lds, err);
     const bool rich = !(plan.lean || plan.quadlit);
@@ -757,7 +757,7 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
                 else
                     hipLaunchKernelGGL(wf_extend<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
             } else if (plan.trav == RT_TRAV_PROGRAM) {
-                WF_EXTEND_LS(RT_TRAV_PROGRAM);
+                WF_EXTEND_LS(RT_TRAV_PROGRAM_EXT);
             } else if (plan.trav == RT_TRAV_FAST) {
                 WF_EXTEND_LS(RT_TRAV_FAST);
             } else {
@@ -777,7 +777,7 @@ int wavefront_render(WavefrontPool& pool, const DScene* sc, const WavefrontPlan&
                     else
                         hipLaunchKernelGGL(wf_connect<false>, grid_cast, block, plan.lds, stream, sc, S, P, par);
                 } else if (plan.trav == RT_TRAV_PROGRAM) {
-                    hipLaunchKernelGGL(wf_connect_ls<RT_TRAV_PROGRAM>, grid_shade, block, plan.lds, stream, sc, S, P, par);
+                    hipLaunchKernelGGL(wf_connect_ls<RT_TRAV_PROGRAM_EXT>, grid_shade, block, plan.lds, stream, sc, S, P, par);
                 } else if (plan.trav == RT_TRAV_FAST) {
                     hipLaunchKernelGGL(wf_connect_ls<RT_TRAV_FAST>, grid_shade, block, plan.lds, stream, sc, S, P, par);
                 } else {

@@ -431,6 +431,7 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, b
     /* (the sorted variant packs the material index into 16 bits) */
     L.sorted = (flags & RTR_FLAG_SORTED_SHADING) && c->n_materials <= 65535 && mega_sortable(integrator, L.trav, L.lean ? RT_MS_LEAN : (L.quadlit ? RT_MS_QUADLIT : RT_MS_FULL));
     L.lds = stack_bytes(c, L.trav) + (size_t)(L.sorted ? SK_WORDS : park_words(integrator, L.trav)) * RTR_BLOCK * sizeof(double);
+    L.program_ext = c->guarded_program;
     L.stream = c->stream;
     L.P = P;
     L.dry = dry;
@@ -853,7 +854,9 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
         if ((rc = upload(c, c->b_finst, cs.inst.data(), sizeof(FInst) * cs.inst.size()))) return rc;
     }
     c->fast_stack_words = cs.stack_words;
-    c->flat_scene = cs.ok && cs.bvh.empty() && !any_tie;
+    /* (guarded references -- hollow spheres -- are tested by the generic loop of the kernels that know about ties: the
+     * flat kernels carry neither) */
+    c->flat_scene = cs.ok && cs.bvh.empty() && !any_tie && cs.guard_of_ref.empty();
     c->walk_extra_words = cs.n_compiled_subtrees ? cs.stack_words : 0;
     DScene& d = c->ds;
     d.finst = static_cast<const FInst*>(c->b_finst.p);
@@ -1244,7 +1247,7 @@ static int li_run(rtr_context* c, const rtr_render_params* p, const int32_t* ijs
         if (trav == RT_TRAV_FAST)                              \
             RTR_LAUNCH(I, RT_TRAV_FAST);                       \
         else if (trav == RT_TRAV_PROGRAM)                      \
-            RTR_LAUNCH(I, RT_TRAV_PROGRAM);                    \
+            RTR_LAUNCH(I, RT_TRAV_PROGRAM_EXT);                \
         else if (trav == RT_TRAV_MEDIA)                        \
             RTR_LAUNCH(I, RT_TRAV_MEDIA);                      \
         else                                                   \
@@ -1255,7 +1258,7 @@ static int li_run(rtr_context* c, const rtr_render_params* p, const int32_t* ijs
         if (trav == RT_TRAV_FAST)                          \
             RTR_LAUNCH(I, RT_TRAV_FAST);                   \
         else if (trav == RT_TRAV_PROGRAM)                  \
-            RTR_LAUNCH(I, RT_TRAV_PROGRAM);                \
+            RTR_LAUNCH(I, RT_TRAV_PROGRAM_EXT);            \
         else                                               \
             RTR_LAUNCH(I, RT_TRAV_MEDIA);                  \
     } while (0)

@@ -64,6 +64,10 @@ int launch_t(const MegaLaunch& L, std::string& err) {
         if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_TOP, FULLQ);
         RTR_LAUNCH(I, RT_TRAV_TOP, RT_MS_FULL);
     }
+    if (trav == RT_TRAV_PROGRAM && L.program_ext) {
+        if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_PROGRAM_EXT, FULLQ);
+        RTR_LAUNCH(I, RT_TRAV_PROGRAM_EXT, RT_MS_FULL);
+    }
     if (trav == RT_TRAV_PROGRAM) {
         if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_PROGRAM, FULLQ);
         RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);
@@ -78,7 +82,7 @@ template <int I>
 int launch_n1(const MegaLaunch& L, std::string& err) {
     if (L.trav == RT_TRAV_FAST) RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_FULL);
     if (L.trav == RT_TRAV_TOP) RTR_LAUNCH(I, RT_TRAV_TOP, RT_MS_FULL);
-    if (L.trav == RT_TRAV_PROGRAM) RTR_LAUNCH(I, RT_TRAV_PROGRAM, RT_MS_FULL);
+    if (L.trav == RT_TRAV_PROGRAM) RTR_LAUNCH(I, RT_TRAV_PROGRAM_EXT, RT_MS_FULL); /* (one program kernel here: the general one) */
     RTR_LAUNCH(I, RT_TRAV_MEDIA, RT_MS_FULL);
 }
 

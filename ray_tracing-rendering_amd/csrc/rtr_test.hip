@@ -111,7 +111,7 @@ int rtr_test_hits(rtr_context* c, rtr_hit_record* recs, int64_t n) {
     else if (v.trav == RT_TRAV_TOP)
         RTR_HITS(RT_TRAV_TOP);
     else if (v.trav == RT_TRAV_PROGRAM)
-        RTR_HITS(RT_TRAV_PROGRAM);
+        RTR_HITS(RT_TRAV_PROGRAM_EXT);
     else if (v.trav == RT_TRAV_MEDIA)
         RTR_HITS(RT_TRAV_MEDIA);
     else
