@@ -893,12 +893,17 @@ inline void rtc::build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>&
         for (int r = I.ref_first; r < I.ref_first + I.n_ref && ok;) {
             const rtr_node& n = prims[r];
             if (n.reserved & RT_TIE_FLAG) ok = false;
-            if (n.reserved & RT_GUARD_FLAG) ok = false; /* its box tests live in the generic loop (fast_ref_hit) */
             const bool box = box_at(r);
-            const int type = box ? kBox : n.type;
+            /* (a guarded run is read by the kernels of guarded scenes only -- RT_TRAV_FLAT_GUARD --, the others that meet
+             * such an instance scan it through the generic loop) */
+            const bool guarded = (n.reserved & RT_GUARD_FLAG) != 0;
+            const int type = box ? kBox : (guarded ? RTR_NODE_SPHERE + RT_RUN_GUARDED : n.type);
             if (runs.empty() || runs.back().first != type || runs.back().second == RT_RUN_COUNT_MAX) runs.push_back({type, 0});
             ++runs.back().second;
-            if (box) {
+            if (guarded) { /* centre, radius, first guard and guard count (as the integers' bits): six words */
+                data.insert(data.end(), n.f, n.f + 6);
+                r += 1;
+            } else if (box) {
                 const double rec[6] = {n.f[0], n.f[1], n.f[2], n.f[3], prims[r + 1].f[4], n.f[4]}; /* x0 x1 y0 y1 z0 z1 */
                 data.insert(data.end(), rec, rec + 6);
                 r += 6;

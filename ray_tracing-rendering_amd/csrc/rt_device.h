@@ -643,7 +643,7 @@ RT_DEV void wrapper_enter(int type, const double* f, V3& o, V3& d) {
 }
 
 /* defined below (order-free traversal of compiled sub-scenes) */
-template <bool ANY, bool TREES = true, bool WEXIT = ANY, bool TOP = false>
+template <bool ANY, bool TREES = true, bool WEXIT = ANY, bool TOP = false, bool GUARD = false>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const FSub sub, V3 o, V3 d, Real time, Real tmin, Real& tmax,
                                            int& hit_ref, int& hit_inst, const Stack st, const int sp0);
 /* sub-scene 0 (the whole scene where it has no media) out of the scene record itself */
@@ -931,13 +931,13 @@ RT_DEV bool guard_pass(const DScene& sc, int first, int count, V3 o, V3 d, Real 
     }
     return enter;
 }
-template <bool TIES = true, bool WAVE_EXIT = false, bool SHARED = false>
+template <bool TIES = true, bool WAVE_EXIT = false, bool SHARED = false, bool GUARD = TIES>
 RT_DEV bool fast_ref_hit(const DScene& sc, int ref, V3 o, V3 d, const RayDiv& q, Real time, Real tmin, Real tmax, Real& t,
                          int& order) {
     const rtr_node n = ld_const(sc.fprim, ref);
     const int tag = n.reserved;
-    /* (guarded references exist only in scenes that take the kernels with TIES = true: rtr_upload_scene) */
-    if (TIES && (tag & RT_GUARD_FLAG) &&
+    /* (guarded references exist only in scenes that take the kernels with TIES or GUARD: rtr_upload_scene) */
+    if (GUARD && (tag & RT_GUARD_FLAG) &&
         !guard_pass(sc, (int)__double_as_longlong(n.f[4]), (int)__double_as_longlong(n.f[5]), o, d, tmin, tmax))
         return false;
     if (!fast_prim_hit<WAVE_EXIT, SHARED>(n, o, d, q, time, tmin, tmax, t)) return false;
@@ -1089,6 +1089,17 @@ RT_DEV void run_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 
         if (sphere_hit_t<SHARED>(mk(p[0], p[1], p[2]), p[3], o, d, q, tmin, tmax, t)) tmax = t, hit_ref = ref + k;
     }
 }
+#define RT_RUN_GUARDED 6 /* run type code (kernels with GUARD only): records c r first count */
+template <bool SHARED>
+RT_DEV void run_guarded_spheres(const DScene& sc, const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q,
+                                Real tmin, Real& tmax, int& hit_ref) {
+    for (int k = 0; k < cnt; ++k, p += 6) {
+        const int first = (int)__double_as_longlong(p[4]), count = (int)__double_as_longlong(p[5]);
+        Real t;
+        if (guard_pass(sc, first, count, o, d, tmin, tmax) && sphere_hit_t<SHARED>(mk(p[0], p[1], p[2]), p[3], o, d, q, tmin, tmax, t))
+            tmax = t, hit_ref = ref + k;
+    }
+}
 template <bool SHARED>
 RT_DEV void run_moving_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real time, Real tmin,
                                Real& tmax, int& hit_ref) {
@@ -1100,7 +1111,7 @@ RT_DEV void run_moving_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3
     }
 }
 /* every run of the instance, in visiting order (`t == t_max` is accepted: the later reference wins an exact tie) */
-template <bool WEXIT, bool SHARED, bool LANE = false>
+template <bool WEXIT, bool SHARED, bool LANE = false, bool GUARD = false>
 RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv& q, Real time, Real tmin, Real& tmax,
                       int& hit_ref) {
     const RT_CONST_AS double* p = as_const(sc.fscan) + I.scan_first;
@@ -1125,6 +1136,9 @@ RT_DEV void scan_runs(const DScene& sc, const FInst& I, V3 o, V3 d, const RayDiv
         } else if (type == RTR_NODE_SPHERE) {
             run_spheres<SHARED>(p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
             p += 4 * cnt;
+        } else if (GUARD && type == RTR_NODE_SPHERE + RT_RUN_GUARDED) {
+            run_guarded_spheres<SHARED>(sc, p, cnt, ref, o, d, q, tmin, tmax, hit_ref);
+            p += 6 * cnt;
         } else {
             run_moving_spheres<SHARED>(p, cnt, ref, o, d, q, time, tmin, tmax, hit_ref);
             p += 9 * cnt;
@@ -1190,21 +1204,21 @@ RT_DEV bool leaf_refs(const DScene& sc, int r0, int r1, V3 o, V3 d, Real time, R
 #endif
 /* The references of one instance against the ray in the instance's frame: linear scan or box tree.  Returns true when
  * an ANY cast has found its hit.  SHARED: see div_shared. */
-template <bool ANY, bool TREES, bool WEXIT, bool SHARED>
+template <bool ANY, bool TREES, bool WEXIT, bool SHARED, bool GUARD = false>
 __device__ __forceinline__ bool scan_instance(const DScene& sc, const FInst& I, V3 lo, V3 ld, const RayDiv& q, Real time,
                                               Real tmin, Real& tmax, int& hit_ref, int& order, const Stack st, const int sp0) {
     if (!TREES || I.bvh_root < 0) {
         if (SHARED && (I.flags & RT_INST_RUNS)) {
             /* (an ANY cast goes on after its first hit: a lane-level exit inside these loops costs every trip,
              * and most shadow rays reach their light) */
-            scan_runs<WEXIT, SHARED>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
+            scan_runs<WEXIT, SHARED, false, GUARD>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
             return ANY && hit_ref >= 0;
         }
         RT_REGION(WEXIT ? RG_SH_GENERIC : RG_GENERIC);
         const int r0 = I.ref_first, r1 = r0 + I.n_ref;
         for (int r = r0; r < r1; ++r) {
             Real t;
-            if (fast_ref_hit<TREES, WEXIT, false>(sc, r, lo, ld, q, time, tmin, tmax, t, order)) {
+            if (fast_ref_hit<TREES, WEXIT, false, TREES || GUARD>(sc, r, lo, ld, q, time, tmin, tmax, t, order)) {
                 tmax = t;
                 hit_ref = r;
                 if (ANY) return true;
@@ -1328,7 +1342,7 @@ __device__ __forceinline__ bool trace_top(const DScene& sc, const FSub sub, V3 o
     return false;
 }
 
-template <bool ANY, bool TREES, bool WEXIT, bool TOP>
+template <bool ANY, bool TREES, bool WEXIT, bool TOP, bool GUARD>
 __device__ __forceinline__ bool trace_fast(const DScene& sc, const FSub sub, V3 o, V3 d, Real time, Real tmin, Real& tmax,
                                            int& hit_ref, int& hit_inst, const Stack st, const int sp0) {
     /* a sub-scene with a top tree, in a kernel that carries the walk (RT_TRAV_TOP; the others scan its instances in
@@ -1379,9 +1393,9 @@ __device__ __forceinline__ bool trace_fast(const DScene& sc, const FSub sub, V3 
         /* references are numbered instance by instance: a hit of this instance is one with ref >= ref_first */
         bool found;
         if (q.fast)
-            found = scan_instance<ANY, TREES, WEXIT, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref, order, st, sp0);
+            found = scan_instance<ANY, TREES, WEXIT, true, GUARD>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref, order, st, sp0);
         else
-            found = scan_instance<ANY, TREES, WEXIT, false>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref, order, st, sp0);
+            found = scan_instance<ANY, TREES, WEXIT, false, GUARD>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref, order, st, sp0);
         RT_REGION(WEXIT ? RG_SH_SETUP : RG_SETUP);
         if (hit_ref >= I.ref_first) hit_inst = ii;
         if (ANY && found) return true;
@@ -1512,12 +1526,15 @@ RT_DEV void fast_finish(const DScene& sc, V3 o, V3 d, Real time, Real t, int ref
 #define RT_TRAV_MEDIA 1
 #define RT_TRAV_FAST 2
 #define RT_TRAV_PROGRAM 3 /* scenes with media: the step program (struct FStep) */
+#define RT_TRAV_FLAT 4    /* compiled scene without box trees and without tie-capable references */
+#define RT_TRAV_TOP 5     /* RT_TRAV_FAST on a scene whose sub-scene 0 has a top tree (FSub::top_root): per-lane instance walk */
 #define RT_TRAV_PROGRAM_EXT 6 /* template value only: RT_TRAV_PROGRAM whose program may hold guarded steps (FStep kind 3) and media
                                 under wrappers (FStep::n_xf); compiled into the plain program kernels that code cost scenes 9 / 22
                                 7 % / 4 %, so the megakernel has both and picks per scene; the other kernels take this one */
 constexpr bool rt_is_program(int trav) { return trav == RT_TRAV_PROGRAM || trav == RT_TRAV_PROGRAM_EXT; }
-#define RT_TRAV_FLAT 4    /* compiled scene without box trees and without tie-capable references */
-#define RT_TRAV_TOP 5     /* RT_TRAV_FAST on a scene whose sub-scene 0 has a top tree (FSub::top_root): per-lane instance walk */
+#define RT_TRAV_FLAT_GUARD 7 /* template value only: RT_TRAV_FLAT of a scene with guarded references (hollow spheres): type runs with the
+                                guarded run and the guard test in the generic loop; its own variant for the same reason */
+constexpr bool rt_is_flat(int trav) { return trav == RT_TRAV_FLAT || trav == RT_TRAV_FLAT_GUARD; }
 
 /* Run the ray-cast program over [tmin, tmax].  Returns whether anything was hit; then `tmax` is
  * the hit's t and either `med` >= 0 (the step of the medium that scattered the ray) or
@@ -1662,9 +1679,9 @@ __device__ __forceinline__ void medium_finish(const DScene& sc, int med, V3 o, V
 template <int TRAV, bool UV_POSSIBLE = true>
 __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real time, Hit& rec, uint32_t& rng,
                                              const Stack st, Real tmin = 0.001, Real tmax = RT_INF) {
-    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT || TRAV == RT_TRAV_TOP) {
+    if (TRAV == RT_TRAV_FAST || rt_is_flat(TRAV) || TRAV == RT_TRAV_TOP) {
         int ref, inst;
-        if (!trace_fast<false, TRAV != RT_TRAV_FLAT, false, TRAV == RT_TRAV_TOP>(sc, sub_scene0(sc), o, d, time, tmin, tmax, ref, inst, st, 0))
+        if (!trace_fast<false, !rt_is_flat(TRAV), false, TRAV == RT_TRAV_TOP, TRAV == RT_TRAV_FLAT_GUARD>(sc, sub_scene0(sc), o, d, time, tmin, tmax, ref, inst, st, 0))
             return false;
         if (UV_POSSIBLE && sc.needs_uv)
             fast_finish<true>(sc, o, d, time, tmax, ref, inst, rec);
@@ -1688,9 +1705,9 @@ __device__ __forceinline__ bool cast_closest(const DScene& sc, V3 o, V3 d, Real 
 }
 template <int TRAV>
 __device__ __forceinline__ bool cast_shadow(const DScene& sc, V3 o, V3 d, Real tmax, uint32_t& rng, const Stack st) {
-    if (TRAV == RT_TRAV_FAST || TRAV == RT_TRAV_FLAT || TRAV == RT_TRAV_TOP) {
+    if (TRAV == RT_TRAV_FAST || rt_is_flat(TRAV) || TRAV == RT_TRAV_TOP) {
         int ref, inst;
-        return trace_fast<true, TRAV != RT_TRAV_FLAT, true, TRAV == RT_TRAV_TOP>(sc, sub_scene0(sc), o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
+        return trace_fast<true, !rt_is_flat(TRAV), true, TRAV == RT_TRAV_TOP, TRAV == RT_TRAV_FLAT_GUARD>(sc, sub_scene0(sc), o, d, 0.0, 0.001, tmax, ref, inst, st, 0);
     }
     if (rt_is_program(TRAV)) { /* the media behind a blocker still draw */
         int ref, inst, med;

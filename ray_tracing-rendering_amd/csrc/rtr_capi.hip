@@ -71,6 +71,7 @@ struct rtr_context {
     std::mutex cancel_mu;
     int n_materials = 0;
     int n_cus = 256; /* hipDeviceProp.multiProcessorCount */
+    bool flat_guarded = false; /* a flat scene but for guarded references: RT_TRAV_FAST everywhere, RT_TRAV_FLAT_GUARD in the megakernel */
     bool machine_ok = false; /* the compiled scene fits the position word of the traversal machine (rt_machine.h) */
     bool guarded_program = false; /* the step program holds guarded primitives (FStep kind 3) or media under wrappers: not a program of the machine */
 };
@@ -399,7 +400,7 @@ int pick_trav(const rtr_context* c, int flags) {
     return c->flat_scene ? RT_TRAV_FLAT : RT_TRAV_FAST;
 }
 size_t stack_bytes(const rtr_context* c, int trav) {
-    const int words = trav == RT_TRAV_FAST || trav == RT_TRAV_FLAT || trav == RT_TRAV_PROGRAM || trav == RT_TRAV_TOP ? c->fast_stack_words
+    const int words = trav == RT_TRAV_FAST || trav == RT_TRAV_FLAT || trav == RT_TRAV_PROGRAM || trav == RT_TRAV_TOP || trav == RT_TRAV_FLAT_GUARD ? c->fast_stack_words
                                                                       : c->info.stack_words + c->walk_extra_words;
     return (size_t)words * RTR_BLOCK * sizeof(int);
 }
@@ -423,6 +424,8 @@ int launch_mega(rtr_context* c, const RenderK& P, int integrator, int trav_in, b
     /* the flat variants exist for integrators 1 and 4; the others take the general compiled-scene kernel */
     L.trav = trav_in == RT_TRAV_FLAT && integrator != RTR_INTEGRATOR_MIS && integrator != RTR_INTEGRATOR_RR ? RT_TRAV_FAST : trav_in;
     if (L.trav == RT_TRAV_FAST && c->ds.top_root0 >= 0) L.trav = RT_TRAV_TOP; /* many instances: the per-lane walk (FSub) */
+    if (L.trav == RT_TRAV_FAST && c->flat_guarded && (integrator == RTR_INTEGRATOR_MIS || integrator == RTR_INTEGRATOR_RR))
+        L.trav = RT_TRAV_FLAT_GUARD;
     L.integrator = integrator;
     L.stack_words = (int)(stack_bytes(c, L.trav) / (RTR_BLOCK * sizeof(int)));
     L.dsc = static_cast<const DScene*>(c->b_dscene.p);
@@ -857,6 +860,7 @@ int rtr_upload_scene(rtr_context* c, const rtr_scene_desc* s) {
     /* (guarded references -- hollow spheres -- are tested by the generic loop of the kernels that know about ties: the
      * flat kernels carry neither) */
     c->flat_scene = cs.ok && cs.bvh.empty() && !any_tie && cs.guard_of_ref.empty();
+    c->flat_guarded = cs.ok && cs.bvh.empty() && !any_tie && !cs.guard_of_ref.empty(); /* the megakernel's RT_TRAV_FLAT_GUARD */
     c->walk_extra_words = cs.n_compiled_subtrees ? cs.stack_words : 0;
     DScene& d = c->ds;
     d.finst = static_cast<const FInst*>(c->b_finst.p);

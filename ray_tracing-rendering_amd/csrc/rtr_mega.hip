@@ -54,6 +54,10 @@ int launch_t(const MegaLaunch& L, std::string& err) {
         }
         RTR_LAUNCH(I, RT_TRAV_FLAT, RT_MS_FULL);
     }
+    if (trav == RT_TRAV_FLAT_GUARD) {
+        if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_FLAT_GUARD, FULLQ);
+        RTR_LAUNCH(I, RT_TRAV_FLAT_GUARD, RT_MS_FULL);
+    }
     if (trav == RT_TRAV_FAST) {
         if (L.lean) RTR_LAUNCH(I, RT_TRAV_FAST, RT_MS_LEAN);
         if (L.quadlit) RTR_LAUNCH(I, RT_TRAV_FAST, FULLQ);
