@@ -133,7 +133,8 @@ def _cat(parts, dtype):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=dtype)
 
 
-def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta_lights=False, lens=0.0, moved_media=False):
+def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta_lights=False, lens=0.0, moved_media=False,
+                 big_group=False):
     """One scene in front of scene 23's camera (origin (0,3,8), looking at the origin)."""
     rng = np.random.default_rng(seed)
     b = Builder(rng)
@@ -192,6 +193,12 @@ def random_scene(seed, n_objects=24, media=False, hollow=False, ties=True, delta
             top.append(b.translate(b.hlist(grp), pos()))
         else:
             top.append(b.flip_face(b.sphere(pos(), float(rng.uniform(0.2, 0.5)), mat)))
+    if big_group:
+        # dozens of primitives under ONE transform chain (scenes.cpp:278-287: translate(rotate_y(bvh_node(boxes2)))): an
+        # instance with a box tree of its own, which a top tree over the instances walks nested on the same stack
+        grp = [b.sphere(rng.uniform(-1.2, 1.2, 3), float(rng.uniform(0.08, 0.25)), b.random_material()) for _ in range(40)]
+        grp += [b.box(p0, p0 + rng.uniform(0.15, 0.5, 3), b.random_material()) for p0 in rng.uniform(-1.2, 1.0, (6, 3))]
+        top.append(b.translate(b.rotate_y(b.hlist(grp), float(rng.uniform(-40.0, 40.0))), pos((-3.0, 1.2, -4.0), (3.0, 2.5, 0.0))))
     if hollow:  # hollow glass (scenes.cpp:903): negative radius inside a glass sphere
         c = pos()
         glass = b.material(A.MAT_DIELECTRIC, f=[1.5])

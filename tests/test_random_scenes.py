@@ -115,7 +115,8 @@ def test_random_scene_renders_equal_the_oracle(ctx, seed, kw):
     G.residue("random%02d.renders.worst_rel_l2" % seed, worst, 1e-12)
 
 
-TOP_CASES = [c for c in CASES if not (c[1].get("media") or c[1].get("hollow") or c[1].get("moved_media"))]
+TOP_CASES = [c for c in CASES if not (c[1].get("media") or c[1].get("hollow") or c[1].get("moved_media"))] + \
+            [(41, dict(big_group=True)), (42, dict(big_group=True, n_objects=70))]
 
 
 @pytest.fixture
