@@ -27,13 +27,15 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 CASES = [(11, {}), (13, dict(n_objects=90)), (14, dict(media=True)), (15, dict(media=True, n_objects=60)),
          (16, dict(hollow=True)), (17, dict(n_objects=8, ties=True)), (18, dict(media=True, hollow=True)),
-         (19, dict(n_objects=200)), (27, dict(delta_lights=True)), (28, dict(delta_lights=True, media=True))]
+         (19, dict(n_objects=200)), (27, dict(delta_lights=True)), (28, dict(delta_lights=True, media=True)),
+         (32, dict(moved_media=True)), (33, dict(moved_media=True, media=True, n_objects=50))]
 W, H, SPP, N_RAYS = 48, 32, 4, 512
 # the same generator output under the reference's own bvh_node (harness command wrap-bvh: its constructor draws the
 # split axes): fixtures random_<seed>b.*
 BVH_CASES = [(13, dict(n_objects=90)), (15, dict(media=True, n_objects=60)), (16, dict(hollow=True)),
              (18, dict(media=True, hollow=True)), (19, dict(n_objects=200)), (23, dict(media=True, n_objects=100)),
-             (26, dict(n_objects=30, hollow=True)), (28, dict(delta_lights=True, media=True))]
+             (26, dict(n_objects=30, hollow=True)), (28, dict(delta_lights=True, media=True)),
+             (32, dict(moved_media=True)), (33, dict(moved_media=True, media=True, n_objects=50))]
 
 
 def sha(path):

@@ -13,7 +13,9 @@ import _golden as G
 A = G.A
 rtr = G.rtr
 # "<seed>": a flat hittable_list as generated; "<seed>b": the same objects under the reference's own bvh_node
-SEEDS = ["11", "13", "14", "15", "16", "17", "18", "19", "27", "28", "13b", "15b", "16b", "18b", "19b", "23b", "26b", "28b"]
+# 32 / 33: a constant_medium UNDER translate / rotate_y (a step with a transform chain, FStep::xf_first)
+SEEDS = ["11", "13", "14", "15", "16", "17", "18", "19", "27", "28", "32", "33",
+         "13b", "15b", "16b", "18b", "19b", "23b", "26b", "28b", "32b", "33b"]
 W, H, SPP = 48, 32, 4
 
 
