@@ -918,6 +918,7 @@ inline void rtc::build_scan_runs(CompiledScene& cs, const std::vector<rtr_node>&
         for (size_t k = 0; k < runs.size(); ++k)
             I.runs |= (uint64_t)((runs[k].first - RTR_NODE_SPHERE) << RT_RUN_COUNT_BITS | runs[k].second) << (RT_RUN_BITS * k);
         cs.scan.insert(cs.scan.end(), data.begin(), data.end());
+        for (size_t k = 0; k < 6; ++k) I.head[k] = k < data.size() ? data[k] : 0.0;
         I.flags |= RT_INST_RUNS;
     }
     cs.scan.resize(cs.scan.size() + 16, 0.0); /* the two-records-per-trip loads never leave the array */

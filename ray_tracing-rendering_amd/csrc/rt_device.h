@@ -332,6 +332,10 @@ struct FInst {
      * reference's scenes comes in with the record itself instead of through two more dependent loads */
     int32_t xf_type[2];
     double xf_f[2][3];
+    /* the first six words of the instance's packed scan data (a copy of fscan[scan_first ...]): an instance that is ONE
+     * `box` -- translate(rotate_y(box)), the reference's favourite object -- is then complete in this record, and the
+     * per-lane walk of a top tree (trace_top) tests it after one fetch instead of two dependent ones */
+    double head[6];
 };
 #define RT_INST_RUNS_MAX 8
 #define RT_RUN_BITS 8       /* per run: count in the low RT_RUN_COUNT_BITS bits, type code above */
@@ -1068,18 +1072,21 @@ RT_DEV void run_rects(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d,
  * one round trip and no per-run overhead for what were three runs of two; the tests are the rectangle tests above, one
  * after the other (hittable_list.h:33-47). */
 #define RT_RUN_BOX 5 /* run type code (types are stored minus RTR_NODE_SPHERE) */
+/* the six tests of one box record x0 x1 y0 y1 z0 z1 (any pointer kind: packed scan data or an instance record's copy) */
+template <bool WEXIT, bool SHARED, bool LANE, class P>
+RT_DEV void run_box(P p, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax, int& hit_ref) {
+    const Real x0 = p[0], x1 = p[1], y0 = p[2], y1 = p[3], z0 = p[4], z1 = p[5];
+    run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(x0, x1, y0, y1, z1, ref, o, d, q, tmin, tmax, hit_ref);
+    run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(x0, x1, y0, y1, z0, ref + 1, o, d, q, tmin, tmax, hit_ref);
+    run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED, LANE>(x0, x1, z0, z1, y1, ref + 2, o, d, q, tmin, tmax, hit_ref);
+    run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED, LANE>(x0, x1, z0, z1, y0, ref + 3, o, d, q, tmin, tmax, hit_ref);
+    run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED, LANE>(y0, y1, z0, z1, x1, ref + 4, o, d, q, tmin, tmax, hit_ref);
+    run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED, LANE>(y0, y1, z0, z1, x0, ref + 5, o, d, q, tmin, tmax, hit_ref);
+}
 template <bool WEXIT, bool SHARED, bool LANE = false>
 RT_DEV void run_boxes(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
                       int& hit_ref) {
-    for (int k = 0; k < cnt; ++k, p += 6, ref += 6) {
-        const Real x0 = p[0], x1 = p[1], y0 = p[2], y1 = p[3], z0 = p[4], z1 = p[5];
-        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(x0, x1, y0, y1, z1, ref, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_XY_RECT, WEXIT, SHARED, LANE>(x0, x1, y0, y1, z0, ref + 1, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED, LANE>(x0, x1, z0, z1, y1, ref + 2, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_XZ_RECT, WEXIT, SHARED, LANE>(x0, x1, z0, z1, y0, ref + 3, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED, LANE>(y0, y1, z0, z1, x1, ref + 4, o, d, q, tmin, tmax, hit_ref);
-        run_rect<RTR_NODE_YZ_RECT, WEXIT, SHARED, LANE>(y0, y1, z0, z1, x0, ref + 5, o, d, q, tmin, tmax, hit_ref);
-    }
+    for (int k = 0; k < cnt; ++k, p += 6, ref += 6) run_box<WEXIT, SHARED, LANE>(p, ref, o, d, q, tmin, tmax, hit_ref);
 }
 template <bool SHARED>
 RT_DEV void run_spheres(const RT_CONST_AS double* p, int cnt, int ref, V3 o, V3 d, const RayDiv& q, Real tmin, Real& tmax,
@@ -1327,10 +1334,18 @@ __device__ __forceinline__ bool trace_top(const DScene& sc, const FSub sub, V3 o
              * every lane of the wave that is here may (div_shared) */
             RayDiv q = raydiv_make(ld, tmin, origin_ok);
             if (I.flags & RT_INST_SPHERES) raydiv_spheres(q, ld);
-            if (q.fast)
-                scan_runs<false, true, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
-            else
-                scan_runs<false, false, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
+            const bool one_box = I.runs == (uint64_t)(RT_RUN_BOX << RT_RUN_COUNT_BITS | 1); /* its record is I.head */
+            if (q.fast) {
+                if (one_box)
+                    run_box<false, true, true>(I.head, I.ref_first, lo, ld, q, tmin, tmax, hit_ref);
+                else
+                    scan_runs<false, true, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
+            } else {
+                if (one_box)
+                    run_box<false, false, true>(I.head, I.ref_first, lo, ld, q, tmin, tmax, hit_ref);
+                else
+                    scan_runs<false, false, true>(sc, I, lo, ld, q, time, tmin, tmax, hit_ref);
+            }
             found = ANY && hit_ref != before;
         } else {
             found = leaf_refs<true, false, ANY>(sc, I.ref_first, I.ref_first + I.n_ref, lo, ld, time, tmin, tmax, hit_ref, order);
