@@ -202,7 +202,9 @@ typedef struct rtr_scene_desc {
 #define RTR_PIPELINE_MEGAKERNEL 1 /* one lane per pixel, in-register bounce loop     */
 #define RTR_PIPELINE_WAVEFRONT 2  /* SoA path pool in HBM, extend/shade/connect stages over live-block lists; all five
                                      integrators; compiled traversals only (RTR_ERR_UNSUPPORTED for graphs that need the
-                                     reference-order walk or with RTR_FLAG_REFERENCE_ORDER) */
+                                     reference-order walk -- e.g. a list holding a medium under a transform -- or with
+                                     RTR_FLAG_REFERENCE_ORDER; hollow spheres and a medium straight under transforms are
+                                     compiled) */
 
 typedef struct rtr_render_params {
     int32_t image_width;  /* W of the full image (pixel (i,j), j=0 is the bottom row, renderer.h:69-74) */

@@ -324,7 +324,8 @@ struct FInst {
      * `runs` holds up to eight runs of eight bits each, first run lowest: (type - RTR_NODE_SPHERE) << 5 | count (a
      * longer run is cut), 0 ends the list (one scalar register pair: shifting it out needs no indexed access to this
      * record).  Instances with more runs than fit, or with tie-capable references, keep the generic loop over fprim
-     * (RT_INST_RUNS clear).  Type code beyond the node types: RT_RUN_BOX. */
+     * (RT_INST_RUNS clear).  Type codes beyond the node types: RT_RUN_BOX, and RT_RUN_GUARDED in scenes with guarded
+     * references (read by their own kernel variant, RT_TRAV_FLAT_GUARD). */
     int32_t scan_first;
     int32_t pad;
     uint64_t runs;
